@@ -1,0 +1,57 @@
+# Top-level build: the product library + drop-in CLIs (hipcc, gfx950 only) and the oracle.
+#
+#   make            -> voice_synth_amd/lib/libvoicesynth.so, voice_synth_amd/bin/{flowgen_shimmer,vowel}
+#   make oracle     -> oracle/liboracle.so and, when /root/reference exists, oracle/_ref/*
+#
+# -ffp-contract=off everywhere: the float/double rounding sequence is part of the parity
+# contract; the fused variant of the filter uses explicit fma() calls.
+
+ROCM    ?= /opt/rocm
+HIPCC   ?= $(ROCM)/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+
+PKG     := voice_synth_amd
+CSRC    := $(PKG)/csrc
+LIBDIR  := $(PKG)/lib
+BINDIR  := $(PKG)/bin
+
+HIPFLAGS := -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+CFLAGS   := -O2 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Wno-unused-parameter
+
+LIB := $(LIBDIR)/libvoicesynth.so
+
+all: $(LIB) clis
+
+$(LIBDIR) $(BINDIR):
+	mkdir -p $@
+
+$(CSRC)/vs_host.o: $(CSRC)/vs_host.c $(CSRC)/vs_tables.h include/voice_synth.h
+	$(CC) $(CFLAGS) -c -o $@ $<
+
+$(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+
+clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel
+
+$(BINDIR)/%: $(PKG)/cli/%.c $(PKG)/cli/cli_common.h $(LIB) | $(BINDIR)
+	$(CC) -O2 -ffp-contract=off -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lvoicesynth -lm -Wl,-rpath,'$$ORIGIN/../lib'
+
+oracle:
+	$(MAKE) -C oracle all
+
+# resource usage (VGPR/SGPR/LDS/occupancy) of every kernel
+resources:
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(CSRC)/vs_kernels.hip
+
+clean:
+	rm -f $(CSRC)/*.o $(LIB) $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel
+	$(MAKE) -C oracle clean
+
+.PHONY: all clis oracle resources clean

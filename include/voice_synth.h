@@ -1,0 +1,212 @@
+/*
+ * voice_synth.h -- C ABI of the MI355X (gfx950) batched vowel-synthesis engine.
+ *
+ * This is the drop-in boundary for ONE hot path of jsansao/voice_synth:
+ *
+ *     flowgen_shimmer (glottal source)  -->  vowel (order-22 all-pole vocal-tract filter)
+ *
+ * The reference exposes no library or FFI surface -- each stage is the body of a main()
+ * (reference flowgen_shimmer.c:246-423 and vowel_new.c:237-331) -- so the entry points
+ * below are what a binding for this path binds instead of those loops.  Every entry cites
+ * the reference lines it replaces.  Plain C types only: pointers, sizes, fixed-width
+ * integers.  No function calls exit(); every failure is a negative return code.
+ *
+ * Threading: a vs_ctx and the plans made from it may be used by one thread at a time.
+ * Different contexts are independent.  There is no global mutable state.
+ *
+ * There is no CPU fallback: if no gfx950 device is usable, vs_ctx_create() fails with
+ * VS_ERR_NODEVICE and nothing can be synthesised.
+ */
+#ifndef VOICE_SYNTH_H
+#define VOICE_SYNTH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_ORDER 22            /* filter order, reference vowel_new.c:172 */
+#define VS_NCOEF (VS_ORDER + 1)
+
+/* return codes */
+#define VS_OK 0
+#define VS_ERR_ARG (-1)          /* NULL pointer, zero size, bad enum */
+#define VS_ERR_RANGE (-2)        /* a parameter the reference would reject with usage() */
+#define VS_ERR_UNSUPPORTED (-3)  /* legal for the reference's parser, but undefined behaviour
+                                    there or beyond this engine's limits */
+#define VS_ERR_HIP (-4)          /* a HIP runtime call failed; see vs_ctx_last_hip_error() */
+#define VS_ERR_NOMEM (-5)
+#define VS_ERR_NODEVICE (-6)     /* no usable gfx950 device: there is no CPU path */
+#define VS_ERR_IO (-7)
+#define VS_USAGE (-8)            /* argv parsers: the reference would print usage() and exit(0) */
+
+/* vs_lane.flags: which perturbation options were GIVEN on the command line.  The reference
+ * tests "arg.X != -1" (flowgen_shimmer.c:248, 295, 373), not only the value. */
+#define VS_FLAG_JITTER 0x1u
+#define VS_FLAG_SHIMMER 0x2u
+#define VS_FLAG_NOISE 0x4u
+
+/* vs_lane.vowel: the reference's -v menu (vowel_new.c:153-156, 548-627) or an explicit
+ * coefficient set. */
+#define VS_VOWEL_CUSTOM 0
+
+/*
+ * One utterance ("lane").  Source fields are struct PAR of flowgen_shimmer.c:73-87 AFTER
+ * initialization() (flowgen_shimmer.c:463-546) has converted the command-line units;
+ * filter fields are the globals of vowel_new.c:76-77 plus the coefficient choice.
+ * Duration is not per lane: a batch has one sample count (see vs_num_samples()).
+ */
+typedef struct vs_lane {
+  float jitter;       /* mean jitter as a fraction: "-j x" / 100            fg:477 */
+  float cq;           /* closed quotient                                    fg:490 */
+  float K;            /* speed of closure                                   fg:484 */
+  float Fg;           /* glottal formant, validation only                   fg:496 */
+  float F0;           /* fundamental frequency, 50 <= F0 < Fg               fg:504 */
+  float DC;           /* ABSOLUTE DC flow: "-l x" * amp, or 0.25 after -n   fg:182,524 */
+  float noise;        /* linear SNR: pow(10, "-n x" / 10)                   fg:511 */
+  float Kvar;         /* closure-speed variation                            fg:530 */
+  float shimmer;      /* shimmer as a fraction: "-s x" / 100                fg:544 */
+  int32_t fs;         /* sampling rate                                      fg:538 */
+  int32_t amp;        /* maximum amplitude                                  fg:518 */
+  uint32_t flags;     /* VS_FLAG_* */
+  uint64_t seed;      /* Philox key of this lane's draw stream (replaces srandom(time), fg:241) */
+  float gain;         /* vowel -g                                           vw:131 */
+  float pre_emphasis; /* vowel -p                                           vw:126 */
+  int32_t vowel;      /* 'a','i','u','1'..'7', or VS_VOWEL_CUSTOM           vw:152 */
+  int32_t reserved;
+  double A[VS_NCOEF]; /* A(z) when vowel == VS_VOWEL_CUSTOM; A[0] must be 1.0 */
+} vs_lane;
+
+/* Per-cycle diagnostics the reference prints inside its loop (flowgen_shimmer.c:307, 409).
+ * Only the single-utterance CLI asks for them. */
+typedef struct vs_cycle_rec {
+  float S;      /* shimmer draw of the cycle ("%5.2f \n"), 0 when shimmer is off */
+  float x_pow;  /* open-phase power   fg:378 */
+  float w_pow;  /* noise power        fg:407 ; SNRdb = 10*log10(x_pow / w_pow) */
+  int32_t T;    /* period of the cycle in samples */
+} vs_cycle_rec;
+
+/* Arithmetic of the filter recurrence.
+ * VS_ARITH_EXACT: products and subtractions rounded one by one in the reference's order
+ *                 (vowel_new.c:279-281); the double state equals the reference's bit for bit.
+ * VS_ARITH_FMA:   22 fused multiply-adds in four partial sums; state differs in the last
+ *                 bits, int16 output differs by +-1 LSB on the order of 1e-9 of samples. */
+#define VS_ARITH_EXACT 0
+#define VS_ARITH_FMA 1
+
+/* What a plan launch computes. */
+#define VS_KIND_SYNTH 0   /* source -> filter, flow never leaves the chip      (fg:246-423 + vw:237-331) */
+#define VS_KIND_SOURCE 1  /* source only: int16 glottal flow                   (fg:246-423) */
+#define VS_KIND_FILTER 2  /* filter only: int16 flow in, int16 speech out      (vw:237-331) */
+
+typedef struct vs_ctx vs_ctx;
+typedef struct vs_plan vs_plan;
+
+/* ---- parameter helpers (host only, no device needed) -------------------------------- */
+
+/* Reference defaults: par initialiser flowgen_shimmer.c:87, vowel_new.c:76-77, vowel 'a'. */
+int vs_lane_defaults(vs_lane *lane);
+
+/* nSamples = (unsigned long) par.fs * par.dur, a FLOAT product (flowgen_shimmer.c:242). */
+int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples);
+
+/* The denominator tables of coefficients(), vowel_new.c:430-633.  A receives 23 doubles. */
+int vs_vowel_coefficients(int vowel, double *A);
+/* The label coefficients() prints for the entry ("/a/ JPHS", ...), vowel_new.c:550-622. */
+const char *vs_vowel_name(int vowel);
+
+/* Range checks of initialization() (flowgen_shimmer.c:470-546) and of vowel's option loop
+ * (vowel_new.c:126-143).  VS_ERR_RANGE where the reference prints usage(); VS_ERR_UNSUPPORTED
+ * where the reference would run into undefined behaviour or this engine's limits. */
+int vs_lane_validate(const vs_lane *lane);
+
+const char *vs_strerror(int code);
+
+/* ---- command-line surface (host only) ------------------------------------------------ */
+
+typedef struct vs_flowgen_cmd {
+  vs_lane lane;
+  float dur;            /* -d */
+  int wav_arg;          /* argv index of the output file name (arg.wav, fg:140) */
+} vs_flowgen_cmd;
+
+typedef struct vs_vowel_cmd {
+  float gain, pre_emphasis, snr; /* snr already pow(10, x/10), 0 when -n absent */
+  int vowel;
+  int input_arg, output_arg, noise_arg;
+} vs_vowel_cmd;
+
+/* The option loop + initialization() of flowgen_shimmer.c:128-222, 463-546, without the
+ * exit(): VS_USAGE where the reference calls usage(). */
+int vs_flowgen_parse(int argc, char **argv, vs_flowgen_cmd *cmd);
+/* The option loop of vowel_new.c:116-192. */
+int vs_vowel_parse(int argc, char **argv, vs_vowel_cmd *cmd);
+
+/* RIFF header as the reference lays it out (flowgen_shimmer.c:49-63, 550-565).
+ * header_bytes is 44 (ILP32 build, the standard layout) or 72 (LP64 build).
+ * Returns the number of bytes written into buf (>= 72 must be available) or < 0. */
+int vs_wav_header_write(unsigned char *buf, int header_bytes, int32_t fs, float dur);
+/* Parses either layout (vowel_new.c:196-205 reads its own struct).  Returns header size. */
+int vs_wav_header_read(const unsigned char *buf, size_t avail, int32_t *fs, int *format_tag,
+                       int *bits_per_sample, uint64_t *data_bytes);
+
+/* ---- device context ------------------------------------------------------------------ */
+
+int vs_ctx_create(int device, vs_ctx **ctx);
+void vs_ctx_destroy(vs_ctx *ctx);
+/* Use an existing hipStream_t for all launches of this context (NULL = default stream). */
+int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream);
+int vs_ctx_set_arith(vs_ctx *ctx, int arith);
+int vs_ctx_last_hip_error(const vs_ctx *ctx);
+/* Name, CU count of the device in use. */
+int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count);
+
+/* ---- plans: host preparation once, any number of launches ---------------------------- */
+
+/* Validates the lanes, builds the per-T2 cosine tables with the host libm (flowgen_shimmer.c:
+ * 319, 328 call cos() per sample; T2 = ceil(.5*cq*P) is fixed per utterance), and uploads the
+ * lane records.  The lanes array may be freed afterwards. */
+int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                   vs_plan **plan);
+void vs_plan_destroy(vs_plan *plan);
+
+/* Launch on the context's stream; returns without waiting for the device.
+ *   in_dev   : VS_KIND_FILTER only, int16 [n_lanes][in_pitch] glottal flow (device pointer)
+ *   out_dev  : int16 [n_lanes][out_pitch] (device pointer), out_pitch >= n_samples
+ *   log_dev  : optional vs_cycle_rec [n_lanes][log_pitch] (device pointer) or NULL
+ *   ncyc_dev : optional int32 [n_lanes], cycles generated per lane, or NULL */
+int vs_plan_launch(vs_plan *plan, int kind, const int16_t *in_dev, size_t in_pitch,
+                   int16_t *out_dev, size_t out_pitch, vs_cycle_rec *log_dev, size_t log_pitch,
+                   int32_t *ncyc_dev);
+int vs_ctx_synchronize(vs_ctx *ctx);
+
+/* Dynamic LDS bytes per 64-lane workgroup and launch geometry a plan will use. */
+int vs_plan_info(const vs_plan *plan, size_t *lds_bytes, size_t *n_workgroups,
+                 size_t *ring_slots);
+
+/* ---- one-call conveniences over host buffers (allocate, copy, launch, copy back) ----- */
+
+/* fg:246-423 then vw:237-331 for every lane; pcm is int16 [n_lanes][n_samples]. */
+int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *pcm);
+/* fg:246-423; flow is int16 [n_lanes][n_samples].  recs/ncyc optional (NULL). */
+int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *flow,
+              vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc);
+/* vw:237-331; only gain, pre_emphasis, vowel/A of each lane are used. */
+int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+              const int16_t *flow, int16_t *pcm);
+
+/* Raw device memory for callers without a HIP binding of their own (the CLIs). */
+int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr);
+int vs_dev_free(vs_ctx *ctx, void *ptr);
+int vs_dev_upload(vs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* Library version string. */
+const char *vs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOICE_SYNTH_H */

@@ -1,0 +1,268 @@
+"""voice_synth_amd -- Python test/bench driver over the C ABI of libvoicesynth.so.
+
+The product is the C library (include/voice_synth.h, voice_synth_amd/csrc) and the two drop-in
+command-line programs (voice_synth_amd/cli).  This package only wraps the C ABI with numpy
+conveniences for tests/ and bench.py.  Nothing here computes samples: every synthesis call
+goes to the gfx950 kernels and raises if the library or the device is missing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (  # noqa: F401
+    CycleRec,
+    FlowgenCmd,
+    Lane,
+    VowelCmd,
+    VsError,
+    VS_ARITH_EXACT,
+    VS_ARITH_FMA,
+    VS_FLAG_JITTER,
+    VS_FLAG_NOISE,
+    VS_FLAG_SHIMMER,
+    VS_KIND_FILTER,
+    VS_KIND_SOURCE,
+    VS_KIND_SYNTH,
+    check,
+    load,
+)
+
+__all__ = [
+    "Lane",
+    "Engine",
+    "Plan",
+    "default_lane",
+    "parse_flowgen",
+    "parse_vowel",
+    "lane_from_cli",
+    "lanes_from_specs",
+    "num_samples",
+    "vowel_coefficients",
+]
+
+
+def default_lane():
+    lane = Lane()
+    check(load().vs_lane_defaults(C.byref(lane)), "vs_lane_defaults")
+    return lane
+
+
+def _argv(args):
+    arr = (C.c_char_p * (len(args) + 1))()
+    for i, a in enumerate(args):
+        arr[i] = a.encode() if isinstance(a, str) else a
+    arr[len(args)] = None
+    return arr
+
+
+def parse_flowgen(args):
+    """args: flowgen_shimmer's argv[1:] (list of str).  Returns (rc, FlowgenCmd)."""
+    cmd = FlowgenCmd()
+    argv = _argv(["flowgen_shimmer"] + list(args))
+    rc = load().vs_flowgen_parse(len(args) + 1, argv, C.byref(cmd))
+    return rc, cmd
+
+
+def parse_vowel(args):
+    cmd = VowelCmd()
+    argv = _argv(["vowel"] + list(args))
+    rc = load().vs_vowel_parse(len(args) + 1, argv, C.byref(cmd))
+    return rc, cmd
+
+
+def lane_from_cli(flowgen_args, vowel_args, seed=0):
+    """One lane from the two reference command lines (without -o / -i file arguments)."""
+    rc, fc = parse_flowgen(["-o", "x.wav"] + list(flowgen_args))
+    check(rc, "vs_flowgen_parse %r" % (flowgen_args,))
+    rc, vc = parse_vowel(["-i", "x.wav", "-o", "y.wav"] + list(vowel_args))
+    check(rc, "vs_vowel_parse %r" % (vowel_args,))
+    lane = Lane()
+    C.memmove(C.byref(lane), C.byref(fc.lane), C.sizeof(Lane))
+    lane.gain = vc.gain
+    lane.pre_emphasis = vc.pre_emphasis
+    lane.vowel = vc.vowel
+    lane.seed = seed
+    return lane, fc.dur
+
+
+def lanes_from_specs(specs):
+    """specs: iterable of (flowgen_args, vowel_args, seed).  Returns (Lane array, dur).
+
+    Distinct command lines are parsed once by the C parser; lanes that share them only differ
+    in their seed."""
+    specs = list(specs)
+    arr = (Lane * len(specs))()
+    cache = {}
+    dur = None
+    for i, (fa, va, seed) in enumerate(specs):
+        key = (tuple(fa), tuple(va))
+        if key not in cache:
+            cache[key] = lane_from_cli(fa, va, 0)
+        proto, d = cache[key]
+        if dur is None:
+            dur = d
+        elif d != dur:
+            raise ValueError("all lanes of a batch share one duration")
+        C.memmove(C.byref(arr[i]), C.byref(proto), C.sizeof(Lane))
+        arr[i].seed = seed
+    return arr, dur
+
+
+def num_samples(fs, dur):
+    n = C.c_uint64()
+    check(load().vs_num_samples(int(fs), float(dur), C.byref(n)), "vs_num_samples")
+    return int(n.value)
+
+
+def vowel_coefficients(vowel):
+    a = (C.c_double * _ffi.VS_NCOEF)()
+    v = ord(vowel) if isinstance(vowel, str) else int(vowel)
+    check(load().vs_vowel_coefficients(v, a), "vs_vowel_coefficients")
+    return np.array(a[:], dtype=np.float64)
+
+
+def _as_lane_array(lanes):
+    if isinstance(lanes, C.Array):
+        return lanes
+    lanes = list(lanes)
+    arr = (Lane * len(lanes))()
+    for i, l in enumerate(lanes):
+        C.memmove(C.byref(arr[i]), C.byref(l), C.sizeof(Lane))
+    return arr
+
+
+class Engine:
+    """A vs_ctx.  Raises VsError(VS_ERR_NODEVICE) when no gfx950 device is usable."""
+
+    def __init__(self, device=0, arith=VS_ARITH_EXACT, stream=None):
+        self._lib = load()
+        self._ctx = C.c_void_p()
+        check(self._lib.vs_ctx_create(int(device), C.byref(self._ctx)), "vs_ctx_create")
+        self.set_arith(arith)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._ctx:
+            self._lib.vs_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_arith(self, arith):
+        check(self._lib.vs_ctx_set_arith(self._ctx, int(arith)), "vs_ctx_set_arith")
+        self.arith = int(arith)
+
+    def set_stream(self, hip_stream):
+        check(self._lib.vs_ctx_set_stream(self._ctx, C.c_void_p(int(hip_stream))), "vs_ctx_set_stream")
+
+    def synchronize(self):
+        check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cu = C.c_int()
+        check(self._lib.vs_ctx_device_info(self._ctx, name, 128, C.byref(cu)), "vs_ctx_device_info")
+        return name.value.decode(), cu.value
+
+    # ---- host-buffer conveniences ----
+    def synth(self, lanes, n_samples):
+        arr = _as_lane_array(lanes)
+        out = np.empty((len(arr), n_samples), dtype=np.int16)
+        check(self._lib.vs_synth(self._ctx, arr, len(arr), n_samples, out.ctypes.data), "vs_synth")
+        return out
+
+    def source(self, lanes, n_samples, log_cycles=0):
+        arr = _as_lane_array(lanes)
+        out = np.empty((len(arr), n_samples), dtype=np.int16)
+        if log_cycles:
+            recs = (CycleRec * (len(arr) * log_cycles))()
+            ncyc = np.zeros(len(arr), dtype=np.int32)
+            check(
+                self._lib.vs_source(self._ctx, arr, len(arr), n_samples, out.ctypes.data,
+                                    C.addressof(recs), log_cycles, ncyc.ctypes.data),
+                "vs_source",
+            )
+            rec_np = np.frombuffer(recs, dtype=[("S", "<f4"), ("x_pow", "<f4"), ("w_pow", "<f4"), ("T", "<i4")])
+            return out, rec_np.reshape(len(arr), log_cycles).copy(), ncyc
+        check(self._lib.vs_source(self._ctx, arr, len(arr), n_samples, out.ctypes.data, None, 0, None),
+              "vs_source")
+        return out
+
+    def filter(self, lanes, flow):
+        arr = _as_lane_array(lanes)
+        flow = np.ascontiguousarray(flow, dtype=np.int16)
+        assert flow.ndim == 2 and flow.shape[0] == len(arr)
+        out = np.empty_like(flow)
+        check(self._lib.vs_filter(self._ctx, arr, len(arr), flow.shape[1], flow.ctypes.data,
+                                  out.ctypes.data), "vs_filter")
+        return out
+
+    # ---- device-pointer path ----
+    def plan(self, lanes, n_samples):
+        return Plan(self, lanes, n_samples)
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self._lib.vs_dev_alloc(self._ctx, nbytes, C.byref(p)), "vs_dev_alloc")
+        return p.value
+
+    def dev_free(self, ptr):
+        check(self._lib.vs_dev_free(self._ctx, C.c_void_p(ptr)), "vs_dev_free")
+
+    def dev_download(self, ptr, shape, dtype=np.int16):
+        out = np.empty(shape, dtype=dtype)
+        check(self._lib.vs_dev_download(self._ctx, out.ctypes.data, C.c_void_p(ptr), out.nbytes),
+              "vs_dev_download")
+        return out
+
+    def dev_upload(self, ptr, array):
+        array = np.ascontiguousarray(array)
+        check(self._lib.vs_dev_upload(self._ctx, C.c_void_p(ptr), array.ctypes.data, array.nbytes),
+              "vs_dev_upload")
+
+
+class Plan:
+    """A vs_plan: lane records + cos tables resident on the device; launches are asynchronous."""
+
+    def __init__(self, engine, lanes, n_samples):
+        self.engine = engine
+        self._lib = engine._lib
+        arr = _as_lane_array(lanes)
+        self.n_lanes = len(arr)
+        self.n_samples = int(n_samples)
+        self._plan = C.c_void_p()
+        check(self._lib.vs_plan_create(engine._ctx, arr, len(arr), n_samples, C.byref(self._plan)),
+              "vs_plan_create")
+
+    def info(self):
+        lds, wgs, slots = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(self._lib.vs_plan_info(self._plan, C.byref(lds), C.byref(wgs), C.byref(slots)), "vs_plan_info")
+        return {"lds_bytes": lds.value, "workgroups": wgs.value, "ring_slots": slots.value}
+
+    def launch(self, kind, out_ptr, out_pitch=None, in_ptr=None, in_pitch=None, log_ptr=None,
+               log_pitch=0, ncyc_ptr=None):
+        out_pitch = self.n_samples if out_pitch is None else out_pitch
+        in_pitch = self.n_samples if in_pitch is None else in_pitch
+        check(
+            self._lib.vs_plan_launch(self._plan, int(kind), C.c_void_p(in_ptr), in_pitch,
+                                     C.c_void_p(out_ptr), out_pitch, C.c_void_p(log_ptr), log_pitch,
+                                     C.c_void_p(ncyc_ptr)),
+            "vs_plan_launch",
+        )
+
+    def close(self):
+        if self._plan:
+            self._lib.vs_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

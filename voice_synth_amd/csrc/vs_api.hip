@@ -1,0 +1,413 @@
+/*
+ * vs_api.hip -- host side of the C ABI (include/voice_synth.h): device context, plans
+ * (parameter expansion + cos tables + upload) and launches.  C++ only as far as hipcc wants
+ * it; the ABI is plain C.
+ *
+ * Everything that is a pure function of a lane's parameters is evaluated HERE, on the host,
+ * with the reference's operand types, so the device never evaluates a transcendental:
+ *   P  = (int)((float)fs/F0)                     flowgen_shimmer.c:244
+ *   T2 = ceil(0.5*cq*P)                          flowgen_shimmer.c:317
+ *   cos(PI*k/T2), k = 0..T2-1                    flowgen_shimmer.c:319, 328 (same arguments in
+ *                                                both half-pulses; PI is 4.0*atan(1.0), fg:39)
+ *   (float)1.2*P, (float)0.8*P                   flowgen_shimmer.c:290
+ *   (float)1.8*amp, (float)0.2*amp               flowgen_shimmer.c:306
+ * This translation unit is compiled with -ffp-contract=off.
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <new>
+#include <vector>
+
+#include "../../include/voice_synth.h"
+#include "vs_device.h"
+
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, const VsKernelArgs *args,
+                                       unsigned grid, size_t lds_bytes, hipStream_t stream);
+
+#define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
+
+struct vs_ctx {
+  int device;
+  int arith;
+  hipStream_t stream;
+  int last_hip_error;
+  char name[128];
+  int cu_count;
+};
+
+struct vs_plan {
+  vs_ctx *ctx;
+  size_t n_lanes, n_samples;
+  VsDevLane *d_lanes;
+  double *d_costab;
+  int ring_slots;
+  size_t lds_bytes;
+  unsigned grid;
+};
+
+#define VS_HIP(ctx, call)                        \
+  do {                                           \
+    hipError_t e_ = (call);                      \
+    if (e_ != hipSuccess) {                      \
+      (ctx)->last_hip_error = (int)e_;           \
+      return VS_ERR_HIP;                         \
+    }                                            \
+  } while (0)
+
+extern "C" int vs_ctx_create(int device, vs_ctx **out)
+{
+  if (!out) return VS_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VS_ERR_NODEVICE;
+  if (device < 0 || device >= count) return VS_ERR_NODEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VS_ERR_NODEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VS_ERR_NODEVICE; /* code object is gfx950 only */
+  if (hipSetDevice(device) != hipSuccess) return VS_ERR_NODEVICE;
+  vs_ctx *ctx = new (std::nothrow) vs_ctx();
+  if (!ctx) return VS_ERR_NOMEM;
+  ctx->device = device;
+  ctx->arith = VS_ARITH_EXACT;
+  ctx->stream = nullptr;
+  ctx->last_hip_error = 0;
+  snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+  ctx->cu_count = prop.multiProcessorCount;
+  *out = ctx;
+  return VS_OK;
+}
+
+extern "C" void vs_ctx_destroy(vs_ctx *ctx) { delete ctx; }
+
+extern "C" int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return VS_ERR_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return VS_OK;
+}
+
+extern "C" int vs_ctx_set_arith(vs_ctx *ctx, int arith)
+{
+  if (!ctx || (arith != VS_ARITH_EXACT && arith != VS_ARITH_FMA)) return VS_ERR_ARG;
+  ctx->arith = arith;
+  return VS_OK;
+}
+
+extern "C" int vs_ctx_last_hip_error(const vs_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+extern "C" int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count)
+{
+  if (!ctx) return VS_ERR_ARG;
+  if (name && name_len) snprintf(name, name_len, "%s", ctx->name);
+  if (cu_count) *cu_count = ctx->cu_count;
+  return VS_OK;
+}
+
+extern "C" int vs_ctx_synchronize(vs_ctx *ctx)
+{
+  if (!ctx) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VS_OK;
+}
+
+extern "C" int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr)
+{
+  if (!ctx || !ptr) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipMalloc(ptr, bytes ? bytes : 1));
+  return VS_OK;
+}
+extern "C" int vs_dev_free(vs_ctx *ctx, void *ptr)
+{
+  if (!ctx) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipFree(ptr));
+  return VS_OK;
+}
+extern "C" int vs_dev_upload(vs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+  if (!ctx) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VS_OK;
+}
+extern "C" int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+  if (!ctx) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Host expansion of one lane (no device needed; exported for the CPU-side tests)
+ * ---------------------------------------------------------------------------------------- */
+extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
+{
+  int rc = vs_lane_validate(lane);
+  if (rc != VS_OK) return rc;
+  double A[VS_NCOEF];
+  if (lane->vowel == VS_VOWEL_CUSTOM) memcpy(A, lane->A, sizeof(A));
+  else if ((rc = vs_vowel_coefficients(lane->vowel, A)) != VS_OK) return rc;
+  memset(d, 0, sizeof(*d));
+  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j];
+  d->gain = (double)lane->gain;
+  d->pre = (double)lane->pre_emphasis;
+  d->jitter = lane->jitter;
+  d->shimmer = lane->shimmer;
+  d->K = lane->K;
+  d->Kvar = lane->Kvar;
+  d->DC = lane->DC;
+  d->noise = lane->noise;
+  d->amp = lane->amp;
+  const int P = (int)((float)lane->fs / lane->F0);
+  d->P = P;
+  d->T2 = (int)ceil(0.5 * lane->cq * P);
+  d->t_hi = (float)1.2 * P;
+  d->t_lo = (float)0.8 * P;
+  d->a_hi = (float)1.8 * lane->amp;
+  d->a_lo = (float)0.2 * lane->amp;
+  d->dcs = (int32_t)(int16_t)(int32_t)lane->DC;
+  uint32_t f = 0;
+  if ((lane->flags & VS_FLAG_JITTER) && lane->jitter != 0.0) f |= VS_DF_JITTER;
+  if ((lane->flags & VS_FLAG_SHIMMER) && lane->shimmer != 0.0) f |= VS_DF_SHIMMER;
+  if (lane->flags & VS_FLAG_NOISE) f |= VS_DF_NOISE;
+  d->flags = f;
+  /* longest admissible period: T is an integer with (float)T <= t_hi */
+  d->tbound = (f & VS_DF_JITTER) ? (int)floorf(d->t_hi) : P;
+  if (d->tbound < P) d->tbound = P;
+  d->key0 = (uint32_t)lane->seed;
+  d->key1 = (uint32_t)(lane->seed >> 32);
+  d->row = row;
+  return VS_OK;
+}
+
+/* cos(PI*k/T2) with PI the reference's macro 4.0*atan(1.0) (flowgen_shimmer.c:39), which
+ * expands textually: PI*i/T2 == ((4.0*atan(1.0))*i)/T2 */
+extern "C" void vs_cos_row(int T2, double *row)
+{
+  for (int k = 0; k < T2; k++) row[k] = cos(4.0 * atan(1.0) * k / T2);
+}
+
+extern "C" int vs_ring_slots_for(int tmax, int *slots)
+{
+  const int limit = VS_LDS_LIMIT / (VS_WAVE * 2);
+  int need = VS_SS + tmax;
+  if (need > limit) return VS_ERR_UNSUPPORTED;
+  int slack = tmax / 4;
+  if (slack < 32) slack = 32;
+  const char *env = getenv("VS_RING_SLACK"); /* tuning knob for experiments */
+  if (env && *env) slack = atoi(env);
+  if (slack < 0) slack = 0;
+  int c = need + slack;
+  c = (c + 7) & ~7;
+  if (c > limit) c = limit;
+  *slots = c;
+  return VS_OK;
+}
+
+extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                              vs_plan **out)
+{
+  if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
+  if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
+  *out = nullptr;
+  std::vector<VsDevLane> dl;
+  std::vector<double> costab;
+  std::map<int, int> row_of_T2;
+  try {
+    dl.resize(n_lanes);
+  } catch (...) {
+    return VS_ERR_NOMEM;
+  }
+  int tmax = 1;
+  for (size_t l = 0; l < n_lanes; l++) {
+    int rc = vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
+    if (rc != VS_OK) return rc;
+    const int T2 = dl[l].T2;
+    std::map<int, int>::iterator it = row_of_T2.find(T2);
+    if (it == row_of_T2.end()) {
+      const int off = (int)costab.size();
+      costab.resize(costab.size() + (size_t)T2);
+      vs_cos_row(T2, &costab[off]);
+      row_of_T2[T2] = off;
+      dl[l].tab_off = off;
+    } else {
+      dl[l].tab_off = it->second;
+    }
+    if (dl[l].tbound > tmax) tmax = dl[l].tbound;
+  }
+  int slots = 0;
+  int rc = vs_ring_slots_for(tmax, &slots);
+  if (rc != VS_OK) return rc;
+
+  vs_plan *p = new (std::nothrow) vs_plan();
+  if (!p) return VS_ERR_NOMEM;
+  p->ctx = ctx;
+  p->n_lanes = n_lanes;
+  p->n_samples = n_samples;
+  p->d_lanes = nullptr;
+  p->d_costab = nullptr;
+  p->ring_slots = slots;
+  p->lds_bytes = (size_t)slots * VS_WAVE * sizeof(int16_t);
+  p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
+
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, costab.size() * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
+                       ctx->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(p->d_costab, costab.data(), costab.size() * sizeof(double),
+                       hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    if (p->d_lanes) (void)hipFree(p->d_lanes);
+    if (p->d_costab) (void)hipFree(p->d_costab);
+    delete p;
+    return VS_ERR_HIP;
+  }
+  *out = p;
+  return VS_OK;
+}
+
+extern "C" void vs_plan_destroy(vs_plan *p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  if (p->d_lanes) (void)hipFree(p->d_lanes);
+  if (p->d_costab) (void)hipFree(p->d_costab);
+  delete p;
+}
+
+extern "C" int vs_plan_info(const vs_plan *p, size_t *lds_bytes, size_t *n_workgroups,
+                            size_t *ring_slots)
+{
+  if (!p) return VS_ERR_ARG;
+  if (lds_bytes) *lds_bytes = p->lds_bytes;
+  if (n_workgroups) *n_workgroups = p->grid;
+  if (ring_slots) *ring_slots = (size_t)p->ring_slots;
+  return VS_OK;
+}
+
+extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
+                              int16_t *out_dev, size_t out_pitch, vs_cycle_rec *log_dev,
+                              size_t log_pitch, int32_t *ncyc_dev)
+{
+  if (!p || !out_dev) return VS_ERR_ARG;
+  if (kind != VS_KIND_SYNTH && kind != VS_KIND_SOURCE && kind != VS_KIND_FILTER) return VS_ERR_ARG;
+  if (out_pitch < p->n_samples) return VS_ERR_ARG;
+  if (kind == VS_KIND_FILTER && (!in_dev || in_pitch < p->n_samples)) return VS_ERR_ARG;
+  if (log_dev && log_pitch == 0) return VS_ERR_ARG;
+  vs_ctx *ctx = p->ctx;
+  VsKernelArgs a;
+  memset(&a, 0, sizeof(a));
+  a.lanes = p->d_lanes;
+  a.costab = p->d_costab;
+  a.in = in_dev;
+  a.out = out_dev;
+  a.log = (kind == VS_KIND_FILTER) ? nullptr : (void *)log_dev;
+  a.ncyc = ncyc_dev;
+  a.in_pitch = (long)in_pitch;
+  a.out_pitch = (long)out_pitch;
+  a.log_pitch = (long)log_pitch;
+  a.n_lanes = (int)p->n_lanes;
+  a.n_samples = (int)p->n_samples;
+  a.ring_slots = p->ring_slots;
+  /* 16-byte vector stores need every row start 4-byte aligned */
+  int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
+  if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);
+  a.vec_ok = vec;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr, &a, p->grid, p->lds_bytes,
+                               ctx->stream));
+  return VS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One-call conveniences over host buffers
+ * ---------------------------------------------------------------------------------------- */
+static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lanes,
+                       size_t n_samples, const int16_t *in_host, int16_t *out_host,
+                       vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
+{
+  if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
+  vs_plan *plan = nullptr;
+  int rc = vs_plan_create(ctx, lanes, n_lanes, n_samples, &plan);
+  if (rc != VS_OK) return rc;
+  const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
+  const size_t bytes = n_lanes * pitch * sizeof(int16_t);
+  int16_t *d_out = nullptr, *d_in = nullptr;
+  vs_cycle_rec *d_log = nullptr;
+  int32_t *d_ncyc = nullptr;
+  hipError_t e = hipMalloc((void **)&d_out, bytes);
+  if (e == hipSuccess && kind == VS_KIND_FILTER) {
+    e = hipMalloc((void **)&d_in, bytes);
+    if (e == hipSuccess)
+      e = hipMemcpy2DAsync(d_in, pitch * 2, in_host, n_samples * 2, n_samples * 2, n_lanes,
+                           hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess && recs && kind != VS_KIND_FILTER) {
+    e = hipMalloc((void **)&d_log, n_lanes * recs_pitch * sizeof(vs_cycle_rec));
+    if (e == hipSuccess)
+      e = hipMemsetAsync(d_log, 0, n_lanes * recs_pitch * sizeof(vs_cycle_rec), ctx->stream);
+  }
+  if (e == hipSuccess && ncyc && kind != VS_KIND_FILTER)
+    e = hipMalloc((void **)&d_ncyc, n_lanes * sizeof(int32_t));
+  if (e == hipSuccess) {
+    rc = vs_plan_launch(plan, kind, d_in, pitch, d_out, pitch, d_log, recs_pitch, d_ncyc);
+    if (rc == VS_OK)
+      e = hipMemcpy2DAsync(out_host, n_samples * 2, d_out, pitch * 2, n_samples * 2, n_lanes,
+                           hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == VS_OK && e == hipSuccess && d_log)
+      e = hipMemcpyAsync(recs, d_log, n_lanes * recs_pitch * sizeof(vs_cycle_rec),
+                         hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == VS_OK && e == hipSuccess && d_ncyc)
+      e = hipMemcpyAsync(ncyc, d_ncyc, n_lanes * sizeof(int32_t), hipMemcpyDeviceToHost,
+                         ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  }
+  if (d_out) (void)hipFree(d_out);
+  if (d_in) (void)hipFree(d_in);
+  if (d_log) (void)hipFree(d_log);
+  if (d_ncyc) (void)hipFree(d_ncyc);
+  vs_plan_destroy(plan);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    return VS_ERR_HIP;
+  }
+  return rc;
+}
+
+extern "C" int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                        int16_t *pcm)
+{
+  return vs_run_host(ctx, VS_KIND_SYNTH, lanes, n_lanes, n_samples, nullptr, pcm, nullptr, 0,
+                     nullptr);
+}
+
+extern "C" int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         int16_t *flow, vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
+{
+  if (recs && recs_pitch == 0) return VS_ERR_ARG;
+  return vs_run_host(ctx, VS_KIND_SOURCE, lanes, n_lanes, n_samples, nullptr, flow, recs,
+                     recs_pitch, ncyc);
+}
+
+extern "C" int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         const int16_t *flow, int16_t *pcm)
+{
+  if (!flow) return VS_ERR_ARG;
+  return vs_run_host(ctx, VS_KIND_FILTER, lanes, n_lanes, n_samples, flow, pcm, nullptr, 0,
+                     nullptr);
+}

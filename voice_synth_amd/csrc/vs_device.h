@@ -1,0 +1,53 @@
+/*
+ * vs_device.h -- records shared by the host-side plan builder and the gfx950 kernels.
+ */
+#ifndef VS_DEVICE_H
+#define VS_DEVICE_H
+
+#include <stdint.h>
+
+#define VS_WAVE 64 /* lanes per wavefront on gfx950: one utterance per lane */
+#define VS_SS 24   /* samples per filter super-step == size of the rotating y[] register window */
+
+/* device-side lane flags */
+#define VS_DF_JITTER 0x1u  /* -j given and non-zero   (flowgen_shimmer.c:248) */
+#define VS_DF_SHIMMER 0x2u /* -s given and non-zero   (flowgen_shimmer.c:295) */
+#define VS_DF_NOISE 0x4u   /* -n given                (flowgen_shimmer.c:373) */
+
+/* One utterance as the kernel reads it (288 bytes, 16-byte aligned).  Everything that is a
+ * pure function of the lane's parameters is evaluated on the host, in C, with the reference's
+ * operand types (vs_plan.cpp). */
+typedef struct VsDevLane {
+  double a[22];       /* A[1..22]                                      vowel_new.c:279-281 */
+  double gain;        /* (double)gain                                  vowel_new.c:268 */
+  double pre;         /* (double)pre_emphasis                          vowel_new.c:284 */
+  float jitter, shimmer, K, Kvar, DC, noise;
+  float t_hi, t_lo;   /* (float)1.2*P, (float)0.8*P                    flowgen_shimmer.c:290 */
+  float a_hi, a_lo;   /* (float)1.8*amp, (float)0.2*amp                flowgen_shimmer.c:306 */
+  int32_t amp;
+  int32_t P;          /* (int)((float)fs/F0)                           flowgen_shimmer.c:244 */
+  int32_t T2;         /* ceil(0.5*cq*P)                                flowgen_shimmer.c:317 */
+  int32_t tab_off;    /* first entry of this lane's cos(PI*k/T2) row in the table */
+  int32_t tbound;     /* longest period the rejection test admits (P without jitter) */
+  int32_t dcs;        /* (short)par.DC                                 flowgen_shimmer.c:321,335 */
+  uint32_t flags;     /* VS_DF_* */
+  uint32_t key0, key1;/* Philox key */
+  int32_t row;        /* output row of this lane */
+  int32_t pad[4];
+} VsDevLane;
+
+typedef struct VsKernelArgs {
+  const VsDevLane *lanes;
+  const double *costab;
+  const int16_t *in;
+  int16_t *out;
+  void *log;          /* vs_cycle_rec* */
+  int32_t *ncyc;
+  long in_pitch, out_pitch, log_pitch;
+  int n_lanes;
+  int n_samples;
+  int ring_slots;
+  int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
+} VsKernelArgs;
+
+#endif

@@ -1,0 +1,490 @@
+/*
+ * vs_kernels.hip -- gfx950 (MI355X) kernels of the batched vowel synthesiser.
+ *
+ * Mapping: ONE UTTERANCE PER LANE, one 64-lane wavefront per workgroup.  A wavefront
+ * alternates between two lock-step phases that are decoupled by a per-lane ring of int16
+ * glottal-flow samples in LDS (layout [slot][lane], 128 B per slot, conflict-free because a
+ * lane only ever touches its own column):
+ *
+ *   generator round (cycle-major, reference flowgen_shimmer.c:246-423): every lane that has
+ *       room produces its next glottal cycle -- jitter / shimmer recursions with their
+ *       rejection loops, rising and falling half-pulse from a host-built cos table, closed
+ *       phase, closed-phase noise from a counter-based Philox stream (4 draws per block) --
+ *       and appends T samples to its ring column.  Lanes walk the SAME phase of their own
+ *       cycle together, so the branches are nearly wave-uniform although every lane has its
+ *       own period, amplitude and draw counter.
+ *
+ *   filter super-step (sample-major, reference vowel_new.c:266-289): 24 samples of the
+ *       order-22 all-pole recurrence in fp64.  The state y[n-1..n-22] lives in a rotating
+ *       window of 24 double registers (no shifting, no LDS); the 24 int16 results leave as
+ *       three 16-byte stores per lane.  The flow itself never reaches HBM.
+ *
+ * No MFMA: the path is a scalar recurrence per utterance, not a contraction.
+ *
+ * Arithmetic contract: this file is compiled with -ffp-contract=off.  VS_ARITH_EXACT keeps
+ * the reference's rounding sequence operation by operation (mul, then sub, j = 1..22), so the
+ * double state is bit-identical to the C reference; VS_ARITH_FMA is the explicit, opt-in
+ * fused variant.  IEEE fp64 mul/add/fma/div and fp32 mul/add/div are correctly rounded on
+ * gfx950 (HIP's default -fhip-fp32-correctly-rounded-divide-sqrt is kept); cos() values come
+ * from the host libm table; sqrt() is only used under an integer fix-up.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/voice_synth.h"
+#include "vs_device.h"
+
+#define VS_PHILOX_M0 0xD2511F53u
+#define VS_PHILOX_M1 0xCD9E8D57u
+#define VS_PHILOX_W0 0x9E3779B9u
+#define VS_PHILOX_W1 0xBB67AE85u
+
+typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+/* Philox4x32-10 (Salmon et al., SC'11), counter = (blk, 0, 0, 0). */
+__device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1, uint32_t &o0,
+                                          uint32_t &o1, uint32_t &o2, uint32_t &o3)
+{
+  uint32_t c0 = blk, c1 = 0u, c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)VS_PHILOX_M0 * c0;
+    const uint64_t p1 = (uint64_t)VS_PHILOX_M1 * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += VS_PHILOX_W0;
+    k1 += VS_PHILOX_W1;
+  }
+  o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+/* per-lane constants */
+struct VsCfg {
+  float jitter, shimmer, K, Kvar, DC, noise, t_hi, t_lo, a_hi, a_lo;
+  int amp, P, T2, tab_off, tbound, dcs;
+  uint32_t flags, key0, key1;
+};
+
+/* per-lane generator state: the complete carried state of flowgen_shimmer.c's loop
+ * (DeltaPer[0], DeltaShimmer[0], T4, T, CountSamples) plus the draw counter */
+struct VsGen {
+  uint32_t d, blk_idx, b0, b1, b2, b3;
+  float dp0, ds0;
+  int T4, T, g, wpos, cyc;
+};
+
+/* next draw of the lane's sequential stream = what random() returns in the shimmed reference */
+__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, bool active)
+{
+  const uint32_t b = s.d >> 2;
+  const bool need = active && (b != s.blk_idx);
+  if (__any(need)) {
+    uint32_t o0, o1, o2, o3;
+    vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
+    if (need) {
+      s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
+      s.blk_idx = b;
+    }
+  }
+  const uint32_t w = s.d & 3u;
+  const uint32_t v = (w == 0u) ? s.b0 : (w == 1u) ? s.b1 : (w == 2u) ? s.b2 : s.b3;
+  if (active) s.d += 1u;
+  return v >> 1;
+}
+
+/* (signed short) of a double, as gcc/x86-64 converts it: through int32, low 16 bits */
+__device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int)v; }
+
+/* vowel_new.c:413-427 */
+__device__ __forceinline__ int vs_round2int(double x)
+{
+  const double dec = x - floor(x);
+  if (dec > 0.5) x = x + 1.0;
+  if (x > 32767.0) x = 32767.0;
+  else if (x < -32767.0) x = -32767.0;
+  return (int)floor(x);
+}
+
+/* (int)sqrt(v) of the reference (flowgen_shimmer.c:382) for a float-valued v >= 0: the
+ * device sqrt only seeds an exact integer search, so its last-bit rounding cannot matter */
+__device__ __forceinline__ int vs_isqrt_floor(double v)
+{
+  int s = (int)sqrt(v);
+  if (s < 0) s = 0;
+  while ((double)(s + 1) * (double)(s + 1) <= v) ++s;
+  while (s > 0 && (double)s * (double)s > v) --s;
+  return s;
+}
+
+__device__ __forceinline__ void vs_emit(int16_t *ring, int C, int lane, const VsGen &s, int i,
+                                        int v, bool ok)
+{
+  int slot = s.wpos + i;
+  if (slot >= C) slot -= C;
+  if (ok) ring[slot * VS_WAVE + lane] = (int16_t)v;
+}
+
+/*
+ * One generator round: every lane with want == true produces one glottal cycle.
+ * Statement-by-statement restatement of flowgen_shimmer.c:248-423 (see oracle/vs_oracle.c for
+ * the scalar form); loops run in lock-step over the wavefront with per-lane predicates.
+ */
+template <bool LOG>
+__device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int16_t *ring, int C,
+                                                  int lane, int N, bool want,
+                                                  const double *__restrict__ costab,
+                                                  vs_cycle_rec *logrow, int log_cap)
+{
+  /* ---- jitter: fg:248-291 ---- */
+  {
+    const bool on = want && (c.flags & VS_DF_JITTER);
+    const float dp1 = s.dp0; /* DeltaPer[1] = DeltaPer[0] */
+    bool pend = on;
+    while (__any(pend)) {
+      const uint32_t r = vs_draw(c, s, pend);
+      const float J = (float)(((double)r / (2147483647 * 10000.0)) * 40000.0 * (double)c.jitter -
+                              2.0 * (double)c.jitter);
+      const double Jd = (double)J;
+      const float dp0 = (float)((double)dp1 * (2.0 + Jd) / (2.0 - Jd) +
+                                2.0 * (double)c.P * Jd / (2.0 - Jd));
+      const int Tn = vs_short_of(ceil((double)((float)c.P + dp0)));
+      const bool reject = ((float)Tn > c.t_hi) || ((float)Tn < c.t_lo);
+      if (pend) {
+        s.dp0 = dp0;
+        s.T = Tn;
+        pend = reject;
+      }
+    }
+  }
+
+  /* ---- shimmer: fg:293-313 ---- */
+  float Amplitude = (float)c.amp;
+  float S = 0.0f;
+  {
+    const bool on = want && (c.flags & VS_DF_SHIMMER);
+    const float ds1 = s.ds0;
+    bool pend = on;
+    while (__any(pend)) {
+      const uint32_t r = vs_draw(c, s, pend);
+      const float epsilon = (float)r / 2147483648.0f; /* (float)RAND_MAX == 2^31 */
+      const float Sn = (float)((double)epsilon * 4.0 * (double)c.shimmer - 2.0 * (double)c.shimmer);
+      const double Sd = (double)Sn;
+      const float ds0 = (float)((double)ds1 * (2.0 + Sd) / (2.0 - Sd) +
+                                2.0 * (double)c.amp * Sd / (2.0 - Sd));
+      const float An = (float)c.amp + ds0;
+      const bool reject = (An > c.a_hi) || (An < c.a_lo);
+      if (pend) {
+        s.ds0 = ds0;
+        S = Sn;
+        Amplitude = An;
+        pend = reject;
+      }
+    }
+  }
+
+  const int T = s.T;
+  const int T2 = c.T2;
+  const double Ad = (double)Amplitude;
+  float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
+
+  /* ---- rising half-pulse: fg:318-324 ---- */
+  for (int i = 0; __any(want && i < T2); ++i) {
+    const bool act = want && (i < T2);
+    const double cs = costab[c.tab_off + (act ? i : 0)];
+    int xs = vs_short_of(ceil(Ad * 0.5 * (1.0 - cs)));
+    if (act && ((float)xs < c.DC)) {
+      xs = c.dcs;
+      s.T4 = i;
+      psum = 0.0f;
+    }
+    if (act) psum += (float)xs * (float)xs;
+    vs_emit(ring, C, lane, s, i, xs, act && (i < T) && (s.g + i < N));
+  }
+
+  /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
+  float Knew;
+  {
+    const uint32_t r = vs_draw(c, s, want);
+    Knew = (float)((double)c.K *
+                   (1.0 + (double)(2.0f * c.Kvar) * (((1.0 * (double)r) / 2147483647.0) - 0.5)));
+  }
+  const double Kd = (double)Knew;
+
+  /* ---- falling half-pulse: fg:327-332 ---- */
+  int T3 = 2 * T2;
+  {
+    bool run = want;
+    for (int i = T2; __any(run && i < 2 * T2); ++i) {
+      const bool act = run && (i < 2 * T2);
+      const double cs = costab[c.tab_off + (act ? (i - T2) : 0)];
+      const int xs = vs_short_of(ceil(Ad * (Kd * cs - Kd + 1.0)));
+      const bool brk = act && ((float)xs < c.DC);
+      if (brk) {
+        T3 = i;
+        run = false;
+      }
+      const bool keep = act && !brk;
+      if (keep) psum += (float)xs * (float)xs;
+      vs_emit(ring, C, lane, s, i, xs, keep && (i < T) && (s.g + i < N));
+    }
+  }
+
+  float x_pow = 0.0f, w_pow = 0.0f;
+  const bool noisy = want && (c.flags & VS_DF_NOISE);
+
+  /* ---- closed phase without noise: fg:334-336 ---- */
+  for (int i = T3; __any(want && !noisy && i < T); ++i) {
+    const bool act = want && !noisy && (i < T);
+    vs_emit(ring, C, lane, s, i, c.dcs, act && (s.g + i < N));
+  }
+
+  /* ---- closed phase with noise: fg:373-411 ---- */
+  if (__any(noisy)) {
+    x_pow = psum / ((float)T3 - (float)s.T4);
+    const float aux = (float)(1.0 + (double)(((float)T3 - (float)s.T4) / ((float)T)));
+    const float arg = 12.0f * aux * x_pow / c.noise;
+    const int NDW = noisy ? vs_isqrt_floor((double)arg) : 0;
+    const double NDWd = (double)NDW;
+    const double half = NDWd / 2.0;
+    const int T4 = s.T4;
+    const int ntail = (T > T3) ? (T - T3) : 0;
+    const int m = noisy ? (T4 + ntail) : 0; /* draws this cycle: [0,T4) then [T3,T) */
+    const uint32_t d0 = s.d;
+    const uint32_t bfirst = d0 >> 2;
+    const int nblk = (m > 0) ? (int)(((d0 + (uint32_t)m - 1u) >> 2) - bfirst) + 1 : 0;
+    float wsum = 0.0f;
+    for (int bi = 0; __any(bi < nblk); ++bi) {
+      const bool bact = bi < nblk;
+      const uint32_t b = bfirst + (uint32_t)bi;
+      uint32_t o[4];
+      vs_philox(b, c.key0, c.key1, o[0], o[1], o[2], o[3]);
+      if (bact) {
+        s.b0 = o[0]; s.b1 = o[1]; s.b2 = o[2]; s.b3 = o[3];
+        s.blk_idx = b;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
+        const bool act = bact && (q >= 0) && (q < m);
+        const int i = (q < T4) ? q : (T3 + (q - T4));
+        const uint32_t r = o[w] >> 1;
+        /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
+        const double u = (1.0 * (double)r) / 2147483647.0;
+        const int wv = vs_short_of(ceil(u * NDWd - half));
+        if (act) wsum += (float)wv * (float)wv;
+        /* truncate((float)x[i] + w[i]) with x[i] == (short)DC on every noise position */
+        int xv = c.dcs + wv;
+        xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
+        vs_emit(ring, C, lane, s, i, xv, act && (i < T) && (s.g + i < N));
+      }
+    }
+    if (noisy) s.d = d0 + (uint32_t)m;
+    w_pow = wsum / (float)T;
+  }
+
+  if (LOG) {
+    if (want && logrow && s.cyc < log_cap) {
+      vs_cycle_rec rec;
+      rec.S = S;
+      rec.x_pow = noisy ? x_pow : 0.0f;
+      rec.w_pow = noisy ? w_pow : 0.0f;
+      rec.T = T;
+      logrow[s.cyc] = rec;
+    }
+  }
+
+  /* ---- emit bookkeeping: fg:413-423 ---- */
+  if (want) {
+    s.cyc += 1;
+    s.g += T;
+    int wp = s.wpos + T;
+    if (wp >= C) wp -= C;
+    s.wpos = wp;
+  }
+}
+
+template <int ARITH, int KIND, bool LOG>
+__global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) int16_t ring[];
+
+  const int lane = (int)threadIdx.x;
+  const long gl = (long)blockIdx.x * VS_WAVE + lane;
+  const bool valid = gl < (long)args.n_lanes;
+  const VsDevLane *__restrict__ L = args.lanes + (valid ? gl : (long)args.n_lanes - 1);
+  const int N = args.n_samples;
+  const int C = args.ring_slots;
+
+  /* filter constants and state in registers */
+  double a[VS_ORDER + 1];
+  double y[VS_SS];
+  a[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j <= VS_ORDER; ++j) a[j] = L->a[j - 1];
+#pragma unroll
+  for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
+  const double gain = L->gain;
+  const double pre = L->pre;
+  const long row = (long)L->row;
+
+  VsCfg c;
+  VsGen s;
+  if (KIND != VS_KIND_FILTER) {
+    c.jitter = L->jitter; c.shimmer = L->shimmer; c.K = L->K; c.Kvar = L->Kvar;
+    c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
+    c.a_hi = L->a_hi; c.a_lo = L->a_lo;
+    c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = L->tab_off;
+    c.tbound = L->tbound; c.dcs = L->dcs;
+    c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
+    s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
+    s.dp0 = 0.0f; s.ds0 = 0.0f;
+    s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
+  }
+  vs_cycle_rec *logrow = nullptr;
+  if (LOG && args.log) logrow = (vs_cycle_rec *)args.log + row * args.log_pitch;
+
+  int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+  const int16_t *__restrict__ irow = (KIND == VS_KIND_FILTER) ? args.in + row * args.in_pitch : nullptr;
+
+  int rpos = 0;
+  for (int n = 0; n < N; n += VS_SS) {
+    /* ---- keep every lane's ring at least one super-step ahead ---- */
+    if (KIND != VS_KIND_FILTER) {
+      for (;;) {
+        const bool starving = valid && (s.g < N) && (s.g - n < VS_SS);
+        if (!__any(starving)) break;
+        /* a lane joins the round if its next cycle is certain to fit; a starving lane always
+         * does because ring_slots >= VS_SS + max(tbound) */
+        bool want = valid && (s.g < N) && (s.g - n + c.tbound <= C);
+        while (__any(want)) {
+          vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, args.costab, logrow,
+                                 (int)args.log_pitch);
+          want = want && (s.g < N) && (s.g - n + c.tbound <= C);
+        }
+      }
+    }
+
+    /* ---- fetch 24 flow samples ---- */
+    int xin[VS_SS];
+    if (KIND == VS_KIND_FILTER) {
+      if (args.vec_ok && (n + VS_SS <= N)) {
+#pragma unroll
+        for (int k = 0; k < VS_SS / 8; ++k) {
+          const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+            xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) {
+        int slot = rpos + t;
+        if (slot >= C) slot -= C;
+        xin[t] = (int)ring[slot * VS_WAVE + lane];
+      }
+      rpos += VS_SS;
+      if (rpos >= C) rpos -= C;
+    }
+
+    /* ---- 24 steps of the recurrence, vowel_new.c:266-289 ---- */
+    int outv[VS_SS];
+    if (KIND == VS_KIND_SOURCE) {
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
+    } else {
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) {
+        /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
+        double acc = (double)xin[t] * gain;
+        const double y1 = y[(t + VS_SS - 1) % VS_SS];
+        if (ARITH == VS_ARITH_EXACT) {
+          /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
+           * difference rounded on its own */
+#pragma unroll
+          for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
+        } else {
+          /* four partial sums over the older taps, the newest tap (j = 1) last */
+          double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+          for (int j = 2; j <= VS_ORDER; ++j) {
+            const double yj = y[(t + VS_SS - j) % VS_SS];
+            if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
+            else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
+            else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
+            else p3 = __builtin_fma(-a[j], yj, p3);
+          }
+          acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
+        }
+        /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
+        const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
+        outv[t] = vs_round2int(o);
+        y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+      }
+    }
+
+    /* ---- 24 int16 results: three 16-byte stores per lane ---- */
+    if (valid) {
+      if (args.vec_ok && (n + VS_SS <= N)) {
+#pragma unroll
+        for (int k = 0; k < VS_SS / 8; ++k) {
+          vs_u32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
+          *(vs_u32x4 *)(orow + n + 8 * k) = v;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < VS_SS; ++t)
+          if (n + t < N) orow[n + t] = (int16_t)outv[t];
+      }
+    }
+  }
+
+  if (KIND != VS_KIND_FILTER && args.ncyc && valid) args.ncyc[row] = s.cyc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * launch table
+ * ---------------------------------------------------------------------------------------- */
+typedef void (*vs_kernel_fn)(VsKernelArgs);
+
+template <int ARITH, int KIND>
+static vs_kernel_fn vs_pick_log(bool log)
+{
+  return log ? (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, true>
+             : (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, false>;
+}
+
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, const VsKernelArgs *args,
+                                       unsigned grid, size_t lds_bytes, hipStream_t stream)
+{
+  vs_kernel_fn fn = nullptr;
+  if (arith == VS_ARITH_EXACT) {
+    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH>(log);
+    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
+    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER>(false);
+  } else if (arith == VS_ARITH_FMA) {
+    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_SYNTH>(log);
+    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
+    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_FILTER>(false);
+  }
+  if (!fn) return hipErrorInvalidValue;
+  if (kind == VS_KIND_FILTER) lds_bytes = 0;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(VS_WAVE), lds_bytes, stream, *args);
+  return hipGetLastError();
+}
