@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One vs_ctx on cuda:0 for the whole GPU session.  No skip: on a GPU box a missing
+    library or device must fail loudly."""
+    import voice_synth_amd as vs
+
+    eng = vs.Engine(0)
+    yield eng
+    eng.close()

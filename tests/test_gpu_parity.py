@@ -1,0 +1,79 @@
+"""GPU parity: the gfx950 engine (through the C ABI) against the CPU oracle, bit for bit.
+
+Small seeded batches at sizes the oracle finishes in seconds.  VS_ARITH_EXACT must be
+bit-identical; VS_ARITH_FMA must stay within the north-star tolerance (1e-5 RMS on the
+/32768 scale) and is additionally expected to differ in at most a handful of samples.
+"""
+import numpy as np
+import pytest
+
+import voice_synth_amd as vs
+from voice_synth_amd import configs
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+TOL_RMS_NORMALISED = 1e-5  # BASELINE.json north_star
+
+
+def _lanes(index, n, lane0=0):
+    specs, fs, dur, _ = configs.config_specs(index, n, lane0)
+    lanes, d = vs.lanes_from_specs(specs)
+    return lanes, vs.num_samples(fs, d)
+
+
+def _rms_norm(a, b):
+    d = (a.astype(np.float64) - b.astype(np.float64)) / 32768.0
+    return float(np.sqrt(np.mean(d * d)))
+
+
+@pytest.mark.parametrize("index,n", [(1, 1), (2, 96), (3, 200), (4, 70), (5, 130)])
+def test_source_bit_exact(engine, index, n):
+    lanes, ns = _lanes(index, n)
+    got = engine.source(lanes, ns)
+    want = po.source(lanes, ns)
+    assert np.array_equal(got, want), "flow differs: %d samples" % int((got != want).sum())
+
+
+@pytest.mark.parametrize("index,n", [(1, 1), (2, 96), (3, 200), (4, 70), (5, 130)])
+def test_synth_exact_bit_exact(engine, index, n):
+    lanes, ns = _lanes(index, n)
+    engine.set_arith(vs.VS_ARITH_EXACT)
+    got = engine.synth(lanes, ns)
+    want = po.synth(lanes, ns)
+    assert np.array_equal(got, want), "pcm differs: %d samples" % int((got != want).sum())
+
+
+@pytest.mark.parametrize("index,n", [(2, 96), (3, 200), (5, 130)])
+def test_synth_fma_within_tolerance(engine, index, n):
+    lanes, ns = _lanes(index, n)
+    engine.set_arith(vs.VS_ARITH_FMA)
+    try:
+        got = engine.synth(lanes, ns)
+    finally:
+        engine.set_arith(vs.VS_ARITH_EXACT)
+    want = po.synth(lanes, ns)
+    ndiff = int((got != want).sum())
+    assert _rms_norm(got, want) <= TOL_RMS_NORMALISED
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    assert ndiff <= max(2, got.size // 1000000), ndiff
+
+
+def test_filter_only_bit_exact(engine):
+    lanes, ns = _lanes(3, 64)
+    rng = np.random.default_rng(7)
+    flow = rng.integers(-20000, 20000, size=(64, ns), dtype=np.int16)
+    got = engine.filter(lanes, flow)
+    want = po.filter(lanes, flow)
+    assert np.array_equal(got, want)
+
+
+def test_cycle_log_matches_oracle(engine):
+    lanes, ns = _lanes(3, 5)
+    flow, recs, ncyc = engine.source(lanes, ns, log_cycles=400)
+    for l in range(5):
+        f, r, n, _ = po.source_one(lanes[l], ns, 400)
+        assert n == ncyc[l]
+        assert np.array_equal(f, flow[l])
+        for name in ("S", "x_pow", "w_pow", "T"):
+            assert np.array_equal(recs[l][:n][name], r[name]), name

@@ -1,0 +1,81 @@
+"""The five BASELINE.json configurations as reference command lines.
+
+Every lane is described by the two argv lists the REFERENCE programs would be given plus its
+Philox seed, so the same description drives (a) oracle/_ref (the compiled reference), (b) the
+CPU restatement and (c) the gfx950 engine.  Mappings fixed by the survey:
+  * "shimmer 0.5 dB"  ->  -s 5.76      (the reference's -s is percent amplitude, F10)
+  * "mixed /a,e,i,o,u/" -> vowel tables 1,2,4,6,7 (there is no e/o letter, F11)
+  * 22.05 kHz         ->  omit -r       (an explicit -r 22050 is rejected, F7)
+  * F0 sweeps         ->  per-lane -g with Fg = F0*125/120 + 1 (F8)
+"""
+import numpy as np
+
+MIXED_VOWELS = "12467"
+
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(ctr, key):
+    """Vectorised Philox4x32-10 over numpy uint64 arrays holding 32-bit words (used only to
+    derive per-lane PARAMETERS of config 5; the sample path has its own device statement)."""
+    c = [np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF for x in ctr]
+    k = [np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF for x in key]
+    for _ in range(10):
+        p0 = np.uint64(_M0) * c[0]
+        p1 = np.uint64(_M1) * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k[0]) & 0xFFFFFFFF
+        n1 = p1 & 0xFFFFFFFF
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k[1]) & 0xFFFFFFFF
+        n3 = p0 & 0xFFFFFFFF
+        c = [n0, n1, n2, n3]
+        k = [(k[0] + np.uint64(_W0)) & 0xFFFFFFFF, (k[1] + np.uint64(_W1)) & 0xFFFFFFFF]
+    return c
+
+
+def config_specs(index, n_lanes=None, lane0=0, seed0=1):
+    """Returns (specs, fs, dur, label).  specs[i] = (flowgen_args, vowel_args, seed) of lane
+    lane0+i.  n_lanes defaults to the configuration's full batch."""
+    full = {1: 1, 2: 1024, 3: 65536, 4: 262144, 5: 65536}[index]
+    n = full if n_lanes is None else int(n_lanes)
+    lanes = np.arange(lane0, lane0 + n, dtype=np.int64)
+    if index == 1:
+        fs, dur = 16000, 1.0
+        specs = [(["-r", "16000", "-d", "1"], ["-v", "a"], seed0 + int(l)) for l in lanes]
+        label = "config1: 1 utt /a/ 16 kHz 1 s clean"
+    elif index == 2:
+        fs, dur = 16000, 1.0
+        fa = ["-r", "16000", "-d", "1", "-j", "1", "-s", "5.76"]
+        specs = [(fa, ["-v", "a"], seed0 + int(l)) for l in lanes]
+        label = "config2: batch 1024 /a/ 16 kHz 1 s jitter 1% shimmer 0.5 dB"
+    elif index == 3:
+        fs, dur = 16000, 1.0
+        fa = ["-r", "16000", "-d", "1", "-j", "1", "-s", "5.76", "-n", "20"]
+        specs = [(fa, ["-v", MIXED_VOWELS[int(l) % 5]], seed0 + int(l)) for l in lanes]
+        label = "config3: batch 65536 mixed vowels 16 kHz 1 s jitter+shimmer+noise"
+    elif index == 4:
+        fs, dur = 22050, 2.0
+        fa = ["-d", "2", "-j", "1", "-s", "5.76", "-n", "20"]
+        specs = [(fa, ["-v", MIXED_VOWELS[int(l) % 5]], seed0 + int(l)) for l in lanes]
+        label = "config4: batch 262144 mixed vowels 22.05 kHz 2 s (8 GPU)"
+    elif index == 5:
+        fs, dur = 16000, 1.0
+        # per-lane parameters from Philox key (0xC0FFEE, lane): u0 -> F0, u1 -> table, u2 -> gain
+        w = philox4x32_10([np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)],
+                          [np.full(n, 0xC0FFEE), lanes.astype(np.uint64)])
+        u0 = w[0].astype(np.float64) / 4294967296.0
+        u1 = w[1].astype(np.float64) / 4294967296.0
+        u2 = w[2].astype(np.float64) / 4294967296.0
+        specs = []
+        ids = "aiu1234567"
+        for i, l in enumerate(lanes):
+            f0 = round(80.0 + 220.0 * float(u0[i]), 2)
+            fg = round(f0 * 125.0 / 120.0 + 1.0, 2)
+            gain = round(1.0 + 9.0 * float(u2[i]), 2)
+            fa = ["-r", "16000", "-d", "1", "-f", "%.2f" % f0, "-g", "%.2f" % fg,
+                  "-j", "1", "-s", "5.76", "-n", "20"]
+            va = ["-v", ids[int(u1[i] * 10) % 10], "-g", "%.2f" % gain]
+            specs.append((fa, va, seed0 + int(l)))
+        label = "config5: batch 65536 F0 sweep 80-300 Hz, random vowel table + gain, 16 kHz 1 s"
+    else:
+        raise ValueError("config index 1..5")
+    return specs, fs, dur, label
