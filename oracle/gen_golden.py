@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ from the REFERENCE ITSELF (oracle/_ref, built by oracle/Makefile from
+/root/reference with the Philox random() shim).  TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (the reference does not exist on the GPU box):
+
+    make -C oracle && python3 oracle/gen_golden.py
+
+Outputs (data only -- inputs as command lines + seeds, outputs as int16 payloads):
+    tests/golden/manifest.json   one entry per case: flowgen argv, vowel argv, seed, sample
+                                 count, draw count, sha256 of both payloads
+    tests/golden/cases.npz       flow_<name>, pcm_<name> int16 arrays
+    tests/golden/stdout_*.txt    the reference's stdout for two cases (per-cycle S / SNRdb lines)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as po  # noqa: E402
+from voice_synth_amd import configs  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<i2").tobytes()).hexdigest()
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cases = []
+
+    def add(name, fa, va, seed=0, keep=True):
+        cases.append((name, list(fa), list(va), int(seed), keep))
+
+    # --- RNG-independent known answers of SURVEY.md section 4 (hash pinned there) ---
+    g16 = ["-r", "16000", "-d", "1"]
+    for v in "aiu1234567":
+        add("ka_g16_v%s" % v, g16, ["-v", v], keep=(v in "a1"))
+    add("ka_g16_va_g1", g16, ["-v", "a", "-g", "1"])
+    add("ka_g22_va_g2_p09", ["-d", "2"], ["-v", "a", "-g", "2", "-p", "0.9"])
+    add("ka_f80", g16 + ["-f", "80", "-g", "84"], ["-v", "a"], keep=False)
+    add("ka_f150", g16 + ["-f", "150", "-g", "157"], ["-v", "a"], keep=False)
+    add("ka_f300", g16 + ["-f", "300", "-g", "313"], ["-v", "a"], keep=False)
+
+    # --- RNG-on: lanes of the BASELINE configurations ---
+    for idx, lanes in ((2, [0, 1, 2, 1023]), (3, [0, 1, 2, 3, 4, 65535]), (4, [0, 1, 2, 3, 4]),
+                       (5, [0, 1, 2, 3, 4, 5, 6, 7])):
+        for l in lanes:
+            specs, fs, dur, _ = configs.config_specs(idx, 1, lane0=l)
+            fa, va, seed = specs[0]
+            add("cfg%d_lane%d" % (idx, l), fa, va, seed)
+
+    # --- edge cases of the source (every option, rejection loops under stress) ---
+    add("edge_dc_kvar", g16 + ["-j", "3", "-s", "10", "-n", "5", "-z", "0.5", "-l", "0.1"],
+        ["-v", "u", "-g", "1"], 11)
+    add("edge_jit10_shim50", g16 + ["-j", "10", "-s", "50", "-n", "0"], ["-v", "2"], 12)
+    add("edge_cq07_k08", g16 + ["-f", "300", "-g", "313", "-j", "1", "-s", "3", "-n", "10", "-k", "0.8",
+                                "-c", "0.7"], ["-v", "i"], 13)
+    add("edge_amp_hi", g16 + ["-a", "30000", "-n", "50", "-s", "2"], ["-v", "3", "-g", "1", "-p", "0"], 14)
+    add("edge_amp0", g16 + ["-a", "0", "-n", "10"], ["-v", "a"], 15)
+    add("edge_noise_only", g16 + ["-n", "20"], ["-v", "6", "-p", "0.5"], 16)
+    add("edge_dur_frac", ["-r", "11025", "-d", "0.77", "-j", "2", "-n", "15"], ["-v", "5"], 17)
+    add("edge_dc_max", g16 + ["-l", "0.25", "-n", "25", "-j", "0.5"], ["-v", "7", "-g", "3"], 18)
+    add("edge_cq1", g16 + ["-c", "1", "-j", "5", "-n", "20"], ["-v", "a", "-g", "1"], 19)
+    add("edge_seed64", g16 + ["-j", "1", "-s", "5.76", "-n", "20"], ["-v", "4"], 0xFEDCBA9876543210)
+
+    manifest = []
+    arrays = {}
+    for name, fa, va, seed, keep in cases:
+        res = po.run_reference(fa, va, seed)
+        entry = {
+            "name": name,
+            "flowgen_args": fa,
+            "vowel_args": va,
+            "seed": seed,
+            "n_samples": int(len(res["flow"])),
+            "ndraws": int(res["ndraws"]),
+            "sha256_flow": sha(res["flow"]),
+            "sha256_pcm": sha(res["pcm"]),
+            "stored": bool(keep),
+        }
+        manifest.append(entry)
+        if keep:
+            arrays["flow_" + name] = res["flow"]
+            arrays["pcm_" + name] = res["pcm"]
+        if name in ("cfg3_lane0", "edge_dc_kvar"):
+            with open(os.path.join(OUT, "stdout_%s.txt" % name), "wb") as f:
+                f.write(res["flow_stdout"])
+        print("%-24s n=%6d draws=%6d flow %s pcm %s" %
+              (name, entry["n_samples"], entry["ndraws"], entry["sha256_flow"][:16], entry["sha256_pcm"][:16]))
+
+    # -O2 build of the reference must agree with the -O0 build
+    for name, fa, va, seed, keep in cases[:3] + cases[-3:]:
+        r2 = po.run_reference(fa, va, seed, opt="O2")
+        e = [m for m in manifest if m["name"] == name][0]
+        assert sha(r2["flow"]) == e["sha256_flow"] and sha(r2["pcm"]) == e["sha256_pcm"], name
+
+    np.savez_compressed(os.path.join(OUT, "cases.npz"), **arrays)
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "reference_build": "gcc -O0 -w + oracle/rng_shim.c (LP64)",
+                   "cases": manifest}, f, indent=1)
+    print("wrote %d cases, %d stored payload pairs" % (len(manifest), len(arrays) // 2))
+
+
+if __name__ == "__main__":
+    main()

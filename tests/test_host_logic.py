@@ -1,0 +1,196 @@
+"""Host-side C of the product: the two argv parsers, validation, sample count, RIFF header,
+lane expansion (no device needed).  Mirrors flowgen_shimmer.c:128-222, 463-565 and
+vowel_new.c:116-192; the quirks are the ones SURVEY.md section 0 records."""
+import ctypes as C
+import math
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import voice_synth_amd as vs
+from voice_synth_amd import _ffi
+from oracle import pyoracle as po
+
+F = np.float32
+
+
+def fg(*args):
+    return vs.parse_flowgen(["-o", "f.wav"] + list(args))
+
+
+def test_defaults_match_reference_initialiser():
+    rc, c = fg()
+    assert rc == 0
+    l = c.lane
+    assert (l.jitter, l.DC, l.noise, l.Kvar, l.shimmer, l.flags) == (0, 0, 0, 0, 0, 0)
+    assert F(l.cq) == F(0.55) and F(l.K) == F(0.65) and l.Fg == 125 and l.F0 == 120
+    assert l.fs == 22050 and l.amp == 12000 and c.dur == 1.0
+    assert l.gain == 10.0 and l.pre_emphasis == 1.0 and l.vowel == ord("a")
+
+
+def test_usage_conditions():
+    assert vs.parse_flowgen([])[0] == _ffi.VS_USAGE               # argc < 2
+    assert vs.parse_flowgen(["-r", "16000"])[0] == _ffi.VS_USAGE  # no -o
+    assert vs.parse_flowgen(["-o"])[0] == _ffi.VS_USAGE           # flag without value
+    assert fg("-q", "1")[0] == _ffi.VS_USAGE                      # unknown flag
+    assert fg("stray")[0] == _ffi.VS_USAGE                        # trailing word not starting with 'i'
+    assert fg("ignored")[0] == 0                                  # ... but 'i...' is let through (fg:219)
+    assert fg("-D", "2", "-R", "8000")[0] == 0                    # flags are case-insensitive
+
+
+def test_ranges():
+    assert fg("-d", "0.49")[0] == _ffi.VS_USAGE and fg("-d", "0.5")[0] == 0
+    assert fg("-j", "1001")[0] == _ffi.VS_USAGE and fg("-j", "1000")[0] == 0  # checked after /100
+    assert fg("-k", "0.49")[0] == _ffi.VS_USAGE
+    assert fg("-c", "1.01")[0] == _ffi.VS_USAGE and fg("-c", "0")[0] == 0
+    assert fg("-g", "49")[0] == _ffi.VS_USAGE
+    assert fg("-f", "125")[0] == _ffi.VS_USAGE                   # F0 < Fg (default 125)
+    assert fg("-f", "300", "-g", "313")[0] == 0
+    assert fg("-f", "49", "-g", "60")[0] == _ffi.VS_USAGE
+    assert fg("-n", "51")[0] == _ffi.VS_USAGE and fg("-n", "-1")[0] == _ffi.VS_USAGE
+    assert fg("-a", "32767")[0] == _ffi.VS_USAGE and fg("-a", "32766")[0] == 0
+    assert fg("-l", "0.31")[0] == _ffi.VS_USAGE
+    assert fg("-l", "0.3")[0] == _ffi.VS_USAGE                   # (float)0.3 > 0.3
+    assert fg("-z", "1.1")[0] == _ffi.VS_USAGE
+    assert fg("-s", "101")[0] == _ffi.VS_USAGE
+
+
+def test_quirk_explicit_22050_rejected():
+    assert fg("-r", "22050")[0] == _ffi.VS_USAGE
+    for r in ("44100", "11025", "16000", "8000"):
+        rc, c = fg("-r", r)
+        assert rc == 0 and c.lane.fs == int(r)
+
+
+def test_quirk_noise_sets_dc():
+    rc, c = fg("-n", "20")
+    assert rc == 0 and c.lane.DC == 0.25 and c.lane.flags & vs.VS_FLAG_NOISE
+    assert F(c.lane.noise) == F(math.pow(10, float(F(20.0) / F(10))))
+    rc, c = fg("-n", "20", "-l", "0.1", "-a", "10000")   # -l is applied later and wins
+    assert rc == 0 and F(c.lane.DC) == F(F(0.1) * F(10000))
+
+
+def test_unit_conversions():
+    rc, c = fg("-j", "1", "-s", "5.76")
+    assert F(c.lane.jitter) == F(1.0 / 100.0)
+    assert F(c.lane.shimmer) == F(F(5.76) / F(100))
+    assert c.lane.flags == vs.VS_FLAG_JITTER | vs.VS_FLAG_SHIMMER
+    rc, c = fg("-j", "0")                          # given but zero: flag set, generator stays off
+    assert c.lane.flags == vs.VS_FLAG_JITTER and c.lane.jitter == 0
+
+
+def test_vowel_parser():
+    ok = ["-i", "a.wav", "-o", "b.wav"]
+    rc, c = vs.parse_vowel(ok + ["-v", "4", "-g", "2.5", "-p", "0.25"])
+    assert rc == 0 and c.vowel == ord("4") and c.gain == 2.5 and c.pre_emphasis == 0.25
+    assert vs.parse_vowel(ok)[0] == _ffi.VS_USAGE                       # -v required
+    assert vs.parse_vowel(["-o", "b.wav", "-v", "a"])[0] == _ffi.VS_USAGE  # -i required
+    assert vs.parse_vowel(ok + ["-v", "e"])[0] == _ffi.VS_USAGE         # no 'e' entry (F11)
+    assert vs.parse_vowel(ok + ["-v", "a", "-g", "0.9"])[0] == _ffi.VS_USAGE
+    assert vs.parse_vowel(ok + ["-v", "a", "-p", "1.5"])[0] == _ffi.VS_USAGE
+    assert vs.parse_vowel(ok + ["-v", "a", "-n", "0"])[0] == _ffi.VS_USAGE
+    rc, c = vs.parse_vowel(ok + ["-v", "a", "-n", "20"])
+    assert rc == 0 and c.noise_arg > 0 and F(c.snr) == F(100.0)
+    rc, c = vs.parse_vowel(ok + ["-v", "A"])                            # passes the parser ...
+    assert rc == 0
+    lane = vs.default_lane()
+    lane.vowel = ord("A")                                               # ... but loads nothing (F11)
+    assert vs.load().vs_lane_validate(C.byref(lane)) == _ffi.VS_ERR_UNSUPPORTED
+
+
+def test_num_samples_is_a_float_product():         # flowgen_shimmer.c:242
+    assert vs.num_samples(16000, 1.0) == 16000
+    assert vs.num_samples(22050, 2.0) == 44100
+    assert vs.num_samples(11025, 0.77) == int(F(11025) * F(0.77))
+    assert vs.num_samples(44100, 600.0) == int(F(44100) * F(600.0))
+
+
+def test_validate():
+    v = vs.load().vs_lane_validate
+    lane = vs.default_lane()
+    assert v(C.byref(lane)) == 0
+    lane.cq = 0.0                                   # no pulse: x_pow = 0/0 in the reference
+    assert v(C.byref(lane)) == _ffi.VS_ERR_UNSUPPORTED
+    lane = vs.default_lane(); lane.F0 = 130
+    assert v(C.byref(lane)) == _ffi.VS_ERR_RANGE
+    lane = vs.default_lane(); lane.gain = 0.5
+    assert v(C.byref(lane)) == _ffi.VS_ERR_RANGE
+    lane = vs.default_lane(); lane.vowel = 0; lane.A[0] = 1.0
+    assert v(C.byref(lane)) == 0
+    lane.A[5] = float("nan")
+    assert v(C.byref(lane)) == _ffi.VS_ERR_RANGE
+
+
+def _hdr(nbytes, fs, dur):
+    buf = (C.c_ubyte * 72)()
+    n = vs.load().vs_wav_header_write(buf, nbytes, fs, dur)
+    return bytes(buf[:n])
+
+
+def test_wav_header_44():
+    h = _hdr(44, 16000, 1.0)
+    assert len(h) == 44
+    riff, size, wave, fmt, fmtsize, tag, ch, sps, avg, align, bits, data, dsize = struct.unpack(
+        "<4sI4s4sIHHIIHH4sI", h)
+    assert (riff, wave, fmt, data) == (b"RIFF", b"WAVE", b"fmt ", b"data")
+    assert (size, fmtsize, tag, ch, sps, avg, align, bits, dsize) == (32036, 16, 1, 1, 16000, 32000, 2, 16, 32000)
+
+
+@pytest.mark.skipif(not po.have_reference(), reason="oracle/_ref not built")
+def test_wav_header_72_equals_reference_bytes():
+    for fa, fs, dur in ((["-r", "16000", "-d", "1"], 16000, 1.0), (["-d", "2"], 22050, 2.0),
+                        (["-r", "11025", "-d", "0.77"], 11025, 0.77)):
+        ref = po.run_reference(fa, None, 0)
+        assert _hdr(72, fs, dur) == ref["flow_header"]
+
+
+def test_wav_header_read_both_layouts():
+    rd = vs.load().vs_wav_header_read
+    for nbytes in (44, 72):
+        h = _hdr(nbytes, 22050, 2.0)
+        fs, tag, bits, db = C.c_int32(), C.c_int(), C.c_int(), C.c_uint64()
+        buf = (C.c_ubyte * 72)(*h)
+        assert rd(buf, len(h), C.byref(fs), C.byref(tag), C.byref(bits), C.byref(db)) == nbytes
+        assert (fs.value, tag.value, bits.value, db.value) == (22050, 1, 16, 88200)
+    assert rd((C.c_ubyte * 72)(), 72, None, None, None, None) == _ffi.VS_ERR_IO
+
+
+def test_expand_lane_matches_reference_expressions():
+    lane, dur = vs.lane_from_cli(["-r", "16000", "-d", "1", "-j", "1", "-s", "5.76", "-n", "20"], ["-v", "2"], 7)
+    d = _ffi.DevLane()
+    assert vs.load().vs_expand_lane(C.byref(lane), 5, C.byref(d)) == 0
+    assert d.P == 133 and d.T2 == 37 and d.row == 5       # (int)(16000/120), ceil(.5*.55*133)
+    assert F(d.t_hi) == F(1.2) * F(133) and F(d.t_lo) == F(0.8) * F(133)
+    assert F(d.a_hi) == F(1.8) * F(12000) and F(d.a_lo) == F(0.2) * F(12000)
+    assert d.tbound == 159 and d.dcs == 0 and d.flags == 7
+    assert (d.key0, d.key1) == (7, 0)
+    assert list(d.a) == list(vs.vowel_coefficients("2")[1:])
+    row = (C.c_double * d.T2)()
+    vs.load().vs_cos_row(d.T2, row)
+    assert list(row) == [math.cos(4.0 * math.atan(1.0) * k / d.T2) for k in range(d.T2)]
+
+
+def test_ring_slots():
+    s = C.c_int()
+    assert vs.load().vs_ring_slots_for(159, C.byref(s)) == 0 and s.value >= 24 + 159 and s.value % 8 == 0
+    assert vs.load().vs_ring_slots_for(5000, C.byref(s)) == _ffi.VS_ERR_UNSUPPORTED
+
+
+def test_cli_usage_text_and_exit_code():
+    exe = os.path.join(os.path.dirname(vs.__file__), "bin", "flowgen_shimmer")
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 0 and b"usage:" in r.stdout and b"-o x {Output file" in r.stdout
+    exe = os.path.join(os.path.dirname(vs.__file__), "bin", "vowel")
+    r = subprocess.run([exe], capture_output=True)
+    assert r.returncode == 0 and r.stdout.startswith(b"lxfilter -i file1.wav")
+
+
+@pytest.mark.skipif(not po.have_reference(), reason="oracle/_ref not built")
+def test_cli_usage_text_equals_reference():
+    for name in ("flowgen_shimmer", "vowel"):
+        ours = subprocess.run([os.path.join(os.path.dirname(vs.__file__), "bin", name)], capture_output=True)
+        ref = subprocess.run([os.path.join(po.REF_DIR, name)], capture_output=True)
+        assert ours.stdout == ref.stdout and ours.returncode == ref.returncode == 0

@@ -34,6 +34,23 @@ def main():
             t = min(ts[1:])
             print("%s/%s: %.3f ms  %.1f Msamples/s  %.3f TB/s (2 B/sample)  first %.1f ms" %
                   (name, kname, t * 1e3, n * ns / t / 1e6, 2 * n * ns / t / 1e12, ts[0] * 1e3), flush=True)
+    # filter-only: flow from a source launch as input
+    flow = eng.dev_alloc(n * ns * 2)
+    eng.set_arith(vs.VS_ARITH_EXACT)
+    plan.launch(vs.VS_KIND_SOURCE, flow)
+    eng.synchronize()
+    for arith, name in ((vs.VS_ARITH_EXACT, "exact"), (vs.VS_ARITH_FMA, "fma")):
+        eng.set_arith(arith)
+        ts = []
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            plan.launch(vs.VS_KIND_FILTER, out, in_ptr=flow)
+            eng.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t = min(ts[1:])
+        print("%s/filter: %.3f ms  %.1f Msamples/s  %.3f TB/s (2 B/sample)" %
+              (name, t * 1e3, n * ns / t / 1e6, 2 * n * ns / t / 1e12), flush=True)
+    eng.dev_free(flow)
     eng.dev_free(out)
 
 main()

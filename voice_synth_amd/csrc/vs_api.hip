@@ -46,6 +46,7 @@ struct vs_plan {
   VsDevLane *d_lanes;
   double *d_costab;
   int ring_slots;
+  int ltab_entries;
   size_t lds_bytes;
   unsigned grid;
 };
@@ -197,17 +198,19 @@ extern "C" void vs_cos_row(int T2, double *row)
   for (int k = 0; k < T2; k++) row[k] = cos(4.0 * atan(1.0) * k / T2);
 }
 
+/* Ring capacity in samples per lane.  A lane joins a generator round when its next cycle is
+ * certain to fit (fill + tbound <= slots) and runs a filter super-step when it holds VS_SS
+ * samples, so VS_SS - 1 + max(tbound) is the minimum; lanes with short periods get room for
+ * several cycles per round (floor of VS_RING_MIN slots). */
 extern "C" int vs_ring_slots_for(int tmax, int *slots)
 {
-  const int limit = VS_LDS_LIMIT / (VS_WAVE * 2);
+  const int limit = (VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2); /* leave room for the cos rows */
   int need = VS_SS + tmax;
   if (need > limit) return VS_ERR_UNSUPPORTED;
-  int slack = tmax / 4;
-  if (slack < 32) slack = 32;
-  const char *env = getenv("VS_RING_SLACK"); /* tuning knob for experiments */
-  if (env && *env) slack = atoi(env);
-  if (slack < 0) slack = 0;
-  int c = need + slack;
+  int floor_slots = 192;
+  const char *env = getenv("VS_RING_MIN"); /* tuning knob for experiments */
+  if (env && *env) floor_slots = atoi(env);
+  int c = need > floor_slots ? need : floor_slots;
   c = (c + 7) & ~7;
   if (c > limit) c = limit;
   *slots = c;
@@ -248,6 +251,22 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   int slots = 0;
   int rc = vs_ring_slots_for(tmax, &slots);
   if (rc != VS_OK) return rc;
+  /* cos rows staged per wavefront: sum of the distinct T2 among its 64 lanes, worst wavefront */
+  int ltab_entries = 0;
+  for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
+    int seen[VS_WAVE], nseen = 0, sum = 0;
+    for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) {
+      bool dup = false;
+      for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
+      if (!dup) {
+        seen[nseen++] = dl[l].T2;
+        sum += dl[l].T2;
+      }
+    }
+    if (sum > ltab_entries) ltab_entries = sum;
+  }
+  ltab_entries = (ltab_entries + 1) & ~1;
+  if ((size_t)slots * VS_WAVE * 2 + (size_t)ltab_entries * 8 > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
 
   vs_plan *p = new (std::nothrow) vs_plan();
   if (!p) return VS_ERR_NOMEM;
@@ -257,7 +276,8 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->d_lanes = nullptr;
   p->d_costab = nullptr;
   p->ring_slots = slots;
-  p->lds_bytes = (size_t)slots * VS_WAVE * sizeof(int16_t);
+  p->ltab_entries = ltab_entries;
+  p->lds_bytes = (size_t)slots * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
   p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
 
   hipError_t e = hipSetDevice(ctx->device);
@@ -324,6 +344,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.n_lanes = (int)p->n_lanes;
   a.n_samples = (int)p->n_samples;
   a.ring_slots = p->ring_slots;
+  a.ltab_entries = p->ltab_entries;
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);

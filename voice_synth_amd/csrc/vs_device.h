@@ -48,6 +48,7 @@ typedef struct VsKernelArgs {
   int n_samples;
   int ring_slots;
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
+  int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
 } VsKernelArgs;
 
 #endif

@@ -1,23 +1,24 @@
 /*
  * vs_kernels.hip -- gfx950 (MI355X) kernels of the batched vowel synthesiser.
  *
- * Mapping: ONE UTTERANCE PER LANE, one 64-lane wavefront per workgroup.  A wavefront
- * alternates between two lock-step phases that are decoupled by a per-lane ring of int16
- * glottal-flow samples in LDS (layout [slot][lane], 128 B per slot, conflict-free because a
- * lane only ever touches its own column):
+ * Mapping: ONE UTTERANCE PER LANE, one 64-lane wavefront per workgroup.  The wavefront is
+ * CYCLE-MAJOR: lanes do not share a sample clock.  Each lane owns a column of an int16 ring in
+ * LDS (layout [slot][lane], 128 B per slot; a lane only ever touches its own column) and its
+ * own position n in its own utterance.  The wavefront alternates between
  *
- *   generator round (cycle-major, reference flowgen_shimmer.c:246-423): every lane that has
- *       room produces its next glottal cycle -- jitter / shimmer recursions with their
- *       rejection loops, rising and falling half-pulse from a host-built cos table, closed
- *       phase, closed-phase noise from a counter-based Philox stream (4 draws per block) --
- *       and appends T samples to its ring column.  Lanes walk the SAME phase of their own
- *       cycle together, so the branches are nearly wave-uniform although every lane has its
- *       own period, amplitude and draw counter.
+ *   generator round (reference flowgen_shimmer.c:246-423): every lane with room produces its
+ *       next glottal cycle -- jitter / shimmer recursions with their rejection loops, rising
+ *       and falling half-pulse from a host-built cos table (staged in LDS), closed phase,
+ *       closed-phase noise from a counter-based Philox stream (4 draws per block) -- and
+ *       appends T samples to its ring column.  All lanes walk the SAME phase of their own
+ *       cycle together, so branches stay nearly wave-uniform although every lane has its own
+ *       period, amplitude and draw counter; and
  *
- *   filter super-step (sample-major, reference vowel_new.c:266-289): 24 samples of the
- *       order-22 all-pole recurrence in fp64.  The state y[n-1..n-22] lives in a rotating
- *       window of 24 double registers (no shifting, no LDS); the 24 int16 results leave as
- *       three 16-byte stores per lane.  The flow itself never reaches HBM.
+ *   filter super-steps (reference vowel_new.c:266-289): while a lane holds >= 24 buffered flow
+ *       samples it runs 24 steps of the order-22 all-pole recurrence in fp64.  The state
+ *       y[n-1..n-22] lives in a rotating window of 24 double registers (no shifting, no LDS);
+ *       the 24 int16 results leave as three 16-byte stores per lane at that lane's own n.
+ *       The flow itself never reaches HBM.
  *
  * No MFMA: the path is a scalar recurrence per utterance, not a contraction.
  *
@@ -89,8 +90,12 @@ __device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, bool activ
       s.blk_idx = b;
     }
   }
-  const uint32_t w = s.d & 3u;
-  const uint32_t v = (w == 0u) ? s.b0 : (w == 1u) ? s.b1 : (w == 2u) ? s.b2 : s.b3;
+  /* word (d & 3) of the cached block; written as 64-bit select + shift so that the compiler
+   * does not turn a four-way select into an indexed scratch array */
+  const uint64_t q0 = (uint64_t)s.b0 | ((uint64_t)s.b1 << 32);
+  const uint64_t q1 = (uint64_t)s.b2 | ((uint64_t)s.b3 << 32);
+  const uint64_t q = (s.d & 2u) ? q1 : q0;
+  const uint32_t v = (uint32_t)(q >> ((s.d & 1u) * 32u));
   if (active) s.d += 1u;
   return v >> 1;
 }
@@ -101,10 +106,12 @@ __device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int
 /* vowel_new.c:413-427 */
 __device__ __forceinline__ int vs_round2int(double x)
 {
+  /* branch-free: "if (dec > 0.5) x = x + 1" adds 1.0 or nothing (x + 0.0 only turns -0.0 into
+   * +0.0, both floor to 0); the two-sided clamp is a min/max pair (x is never NaN: the filter
+   * is stable and its input is int16) */
   const double dec = x - floor(x);
-  if (dec > 0.5) x = x + 1.0;
-  if (x > 32767.0) x = 32767.0;
-  else if (x < -32767.0) x = -32767.0;
+  x = x + ((dec > 0.5) ? 1.0 : 0.0);
+  x = (x > 32767.0) ? 32767.0 : ((x < -32767.0) ? -32767.0 : x);
   return (int)floor(x);
 }
 
@@ -131,11 +138,11 @@ __device__ __forceinline__ void vs_emit(int16_t *ring, int C, int lane, const Vs
  * One generator round: every lane with want == true produces one glottal cycle.
  * Statement-by-statement restatement of flowgen_shimmer.c:248-423 (see oracle/vs_oracle.c for
  * the scalar form); loops run in lock-step over the wavefront with per-lane predicates.
+ * ltab is this wavefront's copy of the cos rows in LDS, c.tab_off the lane's row in it.
  */
 template <bool LOG>
 __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int16_t *ring, int C,
-                                                  int lane, int N, bool want,
-                                                  const double *__restrict__ costab,
+                                                  int lane, int N, bool want, const double *ltab,
                                                   vs_cycle_rec *logrow, int log_cap)
 {
   /* ---- jitter: fg:248-291 ---- */
@@ -187,21 +194,29 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
 
   const int T = s.T;
   const int T2 = c.T2;
+  const int room = N - s.g; /* samples of this cycle that still belong to the utterance */
   const double Ad = (double)Amplitude;
+  const double *trow = ltab + c.tab_off;
   float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
 
-  /* ---- rising half-pulse: fg:318-324 ---- */
-  for (int i = 0; __any(want && i < T2); ++i) {
-    const bool act = want && (i < T2);
-    const double cs = costab[c.tab_off + (act ? i : 0)];
-    int xs = vs_short_of(ceil(Ad * 0.5 * (1.0 - cs)));
-    if (act && ((float)xs < c.DC)) {
-      xs = c.dcs;
-      s.T4 = i;
-      psum = 0.0f;
+  /* ---- rising half-pulse: fg:318-324 (four samples per trip so the LDS reads overlap) ---- */
+  for (int i0 = 0; __any(want && i0 < T2); i0 += 4) {
+    double cs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cs[k] = trow[(i0 + k < T2) ? (i0 + k) : 0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + k;
+      const bool act = want && (i < T2);
+      int xs = vs_short_of(ceil(Ad * 0.5 * (1.0 - cs[k])));
+      if (act && ((float)xs < c.DC)) {
+        xs = c.dcs;
+        s.T4 = i;
+        psum = 0.0f;
+      }
+      if (act) psum += (float)xs * (float)xs;
+      vs_emit(ring, C, lane, s, i, xs, act && (i < T) && (i < room));
     }
-    if (act) psum += (float)xs * (float)xs;
-    vs_emit(ring, C, lane, s, i, xs, act && (i < T) && (s.g + i < N));
   }
 
   /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
@@ -217,18 +232,24 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   int T3 = 2 * T2;
   {
     bool run = want;
-    for (int i = T2; __any(run && i < 2 * T2); ++i) {
-      const bool act = run && (i < 2 * T2);
-      const double cs = costab[c.tab_off + (act ? (i - T2) : 0)];
-      const int xs = vs_short_of(ceil(Ad * (Kd * cs - Kd + 1.0)));
-      const bool brk = act && ((float)xs < c.DC);
-      if (brk) {
-        T3 = i;
-        run = false;
+    for (int k0 = 0; __any(run && k0 < T2); k0 += 4) {
+      double cs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cs[k] = trow[(k0 + k < T2) ? (k0 + k) : 0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = T2 + k0 + k;
+        const bool act = run && (k0 + k < T2);
+        const int xs = vs_short_of(ceil(Ad * (Kd * cs[k] - Kd + 1.0)));
+        const bool brk = act && ((float)xs < c.DC);
+        if (brk) {
+          T3 = i;
+          run = false;
+        }
+        const bool keep = act && !brk;
+        if (keep) psum += (float)xs * (float)xs;
+        vs_emit(ring, C, lane, s, i, xs, keep && (i < T) && (i < room));
       }
-      const bool keep = act && !brk;
-      if (keep) psum += (float)xs * (float)xs;
-      vs_emit(ring, C, lane, s, i, xs, keep && (i < T) && (s.g + i < N));
     }
   }
 
@@ -238,7 +259,7 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   /* ---- closed phase without noise: fg:334-336 ---- */
   for (int i = T3; __any(want && !noisy && i < T); ++i) {
     const bool act = want && !noisy && (i < T);
-    vs_emit(ring, C, lane, s, i, c.dcs, act && (s.g + i < N));
+    vs_emit(ring, C, lane, s, i, c.dcs, act && (i < room));
   }
 
   /* ---- closed phase with noise: fg:373-411 ---- */
@@ -259,18 +280,19 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
     for (int bi = 0; __any(bi < nblk); ++bi) {
       const bool bact = bi < nblk;
       const uint32_t b = bfirst + (uint32_t)bi;
-      uint32_t o[4];
-      vs_philox(b, c.key0, c.key1, o[0], o[1], o[2], o[3]);
+      uint32_t o0, o1, o2, o3;
+      vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
       if (bact) {
-        s.b0 = o[0]; s.b1 = o[1]; s.b2 = o[2]; s.b3 = o[3];
+        s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
         s.blk_idx = b;
       }
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+        const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
         const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
         const bool act = bact && (q >= 0) && (q < m);
         const int i = (q < T4) ? q : (T3 + (q - T4));
-        const uint32_t r = o[w] >> 1;
+        const uint32_t r = ow >> 1;
         /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
         const double u = (1.0 * (double)r) / 2147483647.0;
         const int wv = vs_short_of(ceil(u * NDWd - half));
@@ -278,7 +300,7 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
         /* truncate((float)x[i] + w[i]) with x[i] == (short)DC on every noise position */
         int xv = c.dcs + wv;
         xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-        vs_emit(ring, C, lane, s, i, xv, act && (i < T) && (s.g + i < N));
+        vs_emit(ring, C, lane, s, i, xv, act && (i < T) && (i < room));
       }
     }
     if (noisy) s.d = d0 + (uint32_t)m;
@@ -332,16 +354,40 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
   VsCfg c;
   VsGen s;
+  double *ltab = (double *)(ring + (size_t)C * VS_WAVE);
   if (KIND != VS_KIND_FILTER) {
     c.jitter = L->jitter; c.shimmer = L->shimmer; c.K = L->K; c.Kvar = L->Kvar;
     c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
     c.a_hi = L->a_hi; c.a_lo = L->a_lo;
-    c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = L->tab_off;
+    c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = 0;
     c.tbound = L->tbound; c.dcs = L->dcs;
     c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
     s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
     s.dp0 = 0.0f; s.ds0 = 0.0f;
     s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
+
+    /* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its
+     * lanes (one pass for a homogeneous batch).  The host sized the region for the worst
+     * wavefront of the plan (args.ltab_entries). */
+    {
+      const int gtab = L->tab_off;
+      int used = 0;
+      bool pending = valid;
+      while (__any(pending)) {
+        const unsigned long long m = __ballot(pending);
+        const int leader = __builtin_ctzll(m);
+        const int T2s = __builtin_amdgcn_readlane(c.T2, leader);
+        const int gs = __builtin_amdgcn_readlane(gtab, leader);
+        if (used + T2s > args.ltab_entries) __builtin_trap(); /* plan and kernel disagree */
+        for (int k = lane; k < T2s; k += VS_WAVE) ltab[used + k] = args.costab[gs + k];
+        if (pending && c.T2 == T2s) {
+          c.tab_off = used;
+          pending = false;
+        }
+        used += T2s;
+      }
+    }
+    __syncthreads(); /* single-wave workgroup: orders the staging writes before the row reads */
   }
   vs_cycle_rec *logrow = nullptr;
   if (LOG && args.log) logrow = (vs_cycle_rec *)args.log + row * args.log_pitch;
@@ -349,90 +395,85 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   int16_t *__restrict__ orow = args.out + row * args.out_pitch;
   const int16_t *__restrict__ irow = (KIND == VS_KIND_FILTER) ? args.in + row * args.in_pitch : nullptr;
 
-  int rpos = 0;
-  for (int n = 0; n < N; n += VS_SS) {
-    /* ---- keep every lane's ring at least one super-step ahead ---- */
+  int n = 0;     /* this lane's position in its own utterance */
+  int rslot = 0; /* ring slot of sample n */
+  bool live = valid;
+  while (__any(live)) {
+    /* ---- generator rounds: every lane whose next cycle is certain to fit produces it ---- */
     if (KIND != VS_KIND_FILTER) {
-      for (;;) {
-        const bool starving = valid && (s.g < N) && (s.g - n < VS_SS);
-        if (!__any(starving)) break;
-        /* a lane joins the round if its next cycle is certain to fit; a starving lane always
-         * does because ring_slots >= VS_SS + max(tbound) */
-        bool want = valid && (s.g < N) && (s.g - n + c.tbound <= C);
-        while (__any(want)) {
-          vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, args.costab, logrow,
-                                 (int)args.log_pitch);
-          want = want && (s.g < N) && (s.g - n + c.tbound <= C);
-        }
+      bool want = live && (s.g < N) && (s.g - n + c.tbound <= C);
+      while (__any(want)) {
+        vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, ltab, logrow, (int)args.log_pitch);
+        want = live && (s.g < N) && (s.g - n + c.tbound <= C);
       }
     }
 
-    /* ---- fetch 24 flow samples ---- */
-    int xin[VS_SS];
-    if (KIND == VS_KIND_FILTER) {
-      if (args.vec_ok && (n + VS_SS <= N)) {
+    /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
+    while (live && ((KIND == VS_KIND_FILTER) || (s.g - n >= VS_SS) || (s.g >= N))) {
+      int xin[VS_SS];
+      if (KIND == VS_KIND_FILTER) {
+        if (args.vec_ok && (n + VS_SS <= N)) {
 #pragma unroll
-        for (int k = 0; k < VS_SS / 8; ++k) {
-          const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
+          for (int k = 0; k < VS_SS / 8; ++k) {
+            const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
-            xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
+            for (int e = 0; e < 4; ++e) {
+              xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+              xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
+            }
           }
+        } else {
+#pragma unroll
+          for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
         }
       } else {
 #pragma unroll
-        for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < VS_SS; ++t) {
-        int slot = rpos + t;
-        if (slot >= C) slot -= C;
-        xin[t] = (int)ring[slot * VS_WAVE + lane];
-      }
-      rpos += VS_SS;
-      if (rpos >= C) rpos -= C;
-    }
-
-    /* ---- 24 steps of the recurrence, vowel_new.c:266-289 ---- */
-    int outv[VS_SS];
-    if (KIND == VS_KIND_SOURCE) {
-#pragma unroll
-      for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
-    } else {
-#pragma unroll
-      for (int t = 0; t < VS_SS; ++t) {
-        /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-        double acc = (double)xin[t] * gain;
-        const double y1 = y[(t + VS_SS - 1) % VS_SS];
-        if (ARITH == VS_ARITH_EXACT) {
-          /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
-           * difference rounded on its own */
-#pragma unroll
-          for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
-        } else {
-          /* four partial sums over the older taps, the newest tap (j = 1) last */
-          double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-          for (int j = 2; j <= VS_ORDER; ++j) {
-            const double yj = y[(t + VS_SS - j) % VS_SS];
-            if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
-            else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
-            else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
-            else p3 = __builtin_fma(-a[j], yj, p3);
-          }
-          acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
+        for (int t = 0; t < VS_SS; ++t) {
+          int slot = rslot + t;
+          if (slot >= C) slot -= C;
+          xin[t] = (int)ring[slot * VS_WAVE + lane];
         }
-        /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
-        const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
-        outv[t] = vs_round2int(o);
-        y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+        rslot += VS_SS;
+        if (rslot >= C) rslot -= C;
       }
-    }
 
-    /* ---- 24 int16 results: three 16-byte stores per lane ---- */
-    if (valid) {
+      /* 24 steps of the recurrence, vowel_new.c:266-289 */
+      int outv[VS_SS];
+      if (KIND == VS_KIND_SOURCE) {
+#pragma unroll
+        for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < VS_SS; ++t) {
+          /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
+          double acc = (double)xin[t] * gain;
+          const double y1 = y[(t + VS_SS - 1) % VS_SS];
+          if (ARITH == VS_ARITH_EXACT) {
+            /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
+             * difference rounded on its own */
+#pragma unroll
+            for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
+          } else {
+            /* four partial sums over the older taps, the newest tap (j = 1) last */
+            double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+            for (int j = 2; j <= VS_ORDER; ++j) {
+              const double yj = y[(t + VS_SS - j) % VS_SS];
+              if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
+              else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
+              else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
+              else p3 = __builtin_fma(-a[j], yj, p3);
+            }
+            acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
+          }
+          /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
+          const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
+          outv[t] = vs_round2int(o);
+          y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+        }
+      }
+
+      /* 24 int16 results: three 16-byte stores per lane */
       if (args.vec_ok && (n + VS_SS <= N)) {
 #pragma unroll
         for (int k = 0; k < VS_SS / 8; ++k) {
@@ -447,6 +488,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
         for (int t = 0; t < VS_SS; ++t)
           if (n + t < N) orow[n + t] = (int16_t)outv[t];
       }
+      n += VS_SS;
+      if (n >= N) live = false;
     }
   }
 
