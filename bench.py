@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused source->filter hot path on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the fused kernel over one batch of synthetic utterances already
+described in HBM (lane records + cos rows; the int16 PCM is written to HBM).  Workload at every
+N: BASELINE.json configs[2] per GPU -- 65536 utterances, mixed vowels 1/2/4/6/7, 16 kHz, 1 s,
+jitter 1 % + shimmer 0.5 dB (-s 5.76) + glottal noise 20 dB -- i.e. weak scaling, lane keys
+derived from the GLOBAL lane index.  (configs[1], batch 1024, is 16 wavefronts on a 1024-SIMD
+chip and is a parity case, not a throughput case; the north star's target is stated for
+>= 1e4 concurrent utterances.)
+
+Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
+  roofline     : algorithmic 2 B/sample over the kernel's mean duration (HIP events on the
+                 launch stream, inside the timed region) against the 8 TB/s HBM peak, plus the
+                 fp64-VALU view of the same kernel (the path is VALU-bound);
+  cpu_baseline : the CPU oracle (kind "port", OpenMP over lanes) on this box's host cores, on a
+                 bounded sample of the same workload -- rank 0, N = 1 only;
+  gather       : N > 1 only -- the RCCL delivery of all PCM to rank 0, timed on its own AFTER
+                 the timed region (it is not part of `value`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz
+ALGO_BYTES_PER_SAMPLE = 2       # one int16 store; the flow never reaches HBM
+FLOP_PER_SAMPLE = 48            # 22 mul + 22 sub + gain + pre-emphasis mul/sub
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, help="BASELINE.json configuration (1-based), default 3")
+    ap.add_argument("--lanes", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
+    ap.add_argument("--arith", choices=["exact", "fma"], default="exact")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline run time")
+    return ap.parse_args()
+
+
+def cpu_baseline(specs_fn, n_samples, target_s):
+    """The CPU oracle on a bounded sample of the same workload, all host cores."""
+    import voice_synth_amd as vs
+    from oracle import pyoracle as po
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, po.max_threads()))
+    lanes_cal = 4 * cores
+    lanes, _ = vs.lanes_from_specs(specs_fn(lanes_cal))
+    t0 = time.perf_counter()
+    po.synth(lanes, n_samples, threads=cores)
+    t_cal = time.perf_counter() - t0
+    rate = lanes_cal * n_samples / t_cal
+    n_lanes = int(min(131072, max(lanes_cal, target_s * rate / n_samples)))
+    n_lanes = (n_lanes // cores) * cores or cores
+    lanes, _ = vs.lanes_from_specs(specs_fn(n_lanes))
+    t0 = time.perf_counter()
+    po.synth(lanes, n_samples, threads=cores)
+    t = time.perf_counter() - t0
+    return {
+        "value": round(n_lanes * n_samples / t / 1e6, 2),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d utterances x %d samples of the same workload (first lanes), %.1f s, OpenMP over lanes"
+                  % (n_lanes, n_samples, t),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
+                     % (args.gpus, args.gpus))
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    import voice_synth_amd as vs
+    from voice_synth_amd import configs
+    from voice_synth_amd.dist import gather_pcm
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload: per-GPU batch, lane keys from the global lane index ----
+    full = {1: 1, 2: 1024, 3: 65536, 4: 262144 // 8, 5: 65536}[args.config]
+    per_gpu = args.lanes or full
+    lane0 = rank * per_gpu
+    specs, fs, dur, label = configs.config_specs(args.config, per_gpu, lane0=lane0)
+    lanes, d = vs.lanes_from_specs(specs)
+    n_samples = vs.num_samples(fs, d)
+    pitch = (n_samples + 7) & ~7
+
+    arith = vs.VS_ARITH_EXACT if args.arith == "exact" else vs.VS_ARITH_FMA
+    stream = torch.cuda.current_stream(dev)
+    eng = vs.Engine(local_rank, arith=arith, stream=stream.cuda_stream)
+    dev_name, cus = eng.device_info()
+    plan = eng.plan(lanes, n_samples)                     # lane records + cos rows -> HBM
+    out = torch.empty((per_gpu, pitch), dtype=torch.int16, device=dev)
+
+    def launch():
+        plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        launch()
+    sync_all()
+
+    # ---- timed region: exactly K steps, HIP events around every launch on the launch stream ----
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        launch()
+        b.record(stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    k = torch.tensor([sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    kern_ms_avg = float(k.item())
+
+    samples_per_step = per_gpu * n_samples * world
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    # ---- parity spot check of what was just timed (first lanes of this rank) ----
+    check = None
+    if rank == 0:
+        from oracle import pyoracle as po
+        ncheck = min(4, per_gpu)
+        got = out[:ncheck, :n_samples].cpu().numpy()
+        want = po.synth([lanes[i] for i in range(ncheck)], n_samples, threads=1)
+        check = {"lanes": ncheck, "mismatched_samples": int((got != want).sum())}
+
+    # ---- the other arithmetic mode, outside the timed region (3 launches) ----
+    other = vs.VS_ARITH_FMA if arith == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
+    eng.set_arith(other)
+    launch()
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(3):
+        launch()
+    b.record(stream)
+    torch.cuda.synchronize(dev)
+    other_ms = a.elapsed_time(b) / 3.0
+    eng.set_arith(arith)
+
+    # ---- N > 1: delivery of the PCM to rank 0 over RCCL, timed on its own ----
+    gather = None
+    if world > 1 and not args.no_gather:
+        launch()
+        sync_all()
+        local = out[:, :n_samples]
+        g0 = time.perf_counter()
+        full_pcm = gather_pcm(local, per_gpu * world, dst=0)
+        sync_all()
+        g = time.perf_counter() - g0
+        nbytes = per_gpu * (world - 1) * n_samples * 2
+        gather = {"ms": round(g * 1e3, 3), "GB/s": round(nbytes / g / 1e9, 1),
+                  "bytes_into_rank0": nbytes, "included_in_value": False}
+        del full_pcm
+
+    result = None
+    if rank == 0:
+        achieved = ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                rec = json.load(open(pmc_path)).get("config%d_%s_%d" % (args.config, args.arith, per_gpu))
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        tflops = FLOP_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e12
+        result = {
+            "metric": "synthesised Msamples/s (whole node)",
+            "value": round(value, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": label,
+                "baseline_config_index": args.config - 1,
+                "utterances_per_gpu": per_gpu,
+                "samples_per_utterance": n_samples,
+                "sample_rate_hz": fs,
+                "arith": args.arith,
+                "parallelism": "utterances sharded over %d GPU(s), no data-path collective" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": traffic,
+                "kernel": "vs_synth_kernel<%d, 0, false>" % arith,
+                "kernel_ms_avg": round(kern_ms_avg, 4),
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples,
+                "fp64_valu": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
+                              "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
+                              "flop_per_sample": FLOP_PER_SAMPLE},
+            },
+            "other_arith": {"arith": "fma" if arith == vs.VS_ARITH_EXACT else "exact",
+                            "kernel_ms_avg": round(other_ms, 4),
+                            "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
+            "parity_check": check,
+            "device": dev_name.strip(),
+        }
+        if gather:
+            result["gather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(
+                lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+
+    plan.close()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""The two drop-in programs on the GPU: same argv as the reference -> same file bytes (72-byte
+LP64 header variant, which is what the compiled reference writes here) and the same per-cycle
+stdout lines.  Expected data: tests/golden (reference outputs), not the oracle."""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import voice_synth_amd as vs
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = {c["name"]: c for c in json.load(open(os.path.join(GOLD, "manifest.json")))["cases"]}
+BIN = os.path.join(os.path.dirname(vs.__file__), "bin")
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def _run(name, tmp_path, header):
+    c = CASES[name]
+    env = dict(os.environ, VS_SEED=str(c["seed"]), VS_WAV_HEADER=str(header))
+    fg = subprocess.run([os.path.join(BIN, "flowgen_shimmer"), "-o", "g.wav"] + c["flowgen_args"],
+                        cwd=tmp_path, env=env, capture_output=True)
+    assert fg.returncode == 0, fg.stderr
+    vw = subprocess.run([os.path.join(BIN, "vowel"), "-i", "g.wav", "-o", "o.wav"] + c["vowel_args"],
+                        cwd=tmp_path, env=env, capture_output=True)
+    assert vw.returncode == 0, vw.stderr
+    return c, fg, vw, open(tmp_path / "g.wav", "rb").read(), open(tmp_path / "o.wav", "rb").read()
+
+
+@pytest.mark.parametrize("name", ["ka_g16_va", "cfg3_lane0", "edge_dc_kvar", "cfg4_lane2", "edge_dur_frac"])
+@pytest.mark.parametrize("header", [44, 72])
+def test_pipeline_files_match_reference(tmp_path, name, header):
+    c, fg, vw, g, o = _run(name, tmp_path, header)
+    assert len(g) == header + 2 * c["n_samples"] and len(o) == len(g)
+    assert sha(g[header:]) == c["sha256_flow"]
+    assert sha(o[header:]) == c["sha256_pcm"]
+    assert o[:header] == g[:header]                      # vowel copies its input header verbatim
+    assert fg.stdout.endswith(b"done\n") and vw.stdout.endswith(b"Wait...done\n")
+
+
+@pytest.mark.parametrize("name", ["cfg3_lane0", "edge_dc_kvar"])
+def test_flowgen_stdout_equals_reference(tmp_path, name):
+    c, fg, vw, g, o = _run(name, tmp_path, 72)
+    want = open(os.path.join(GOLD, "stdout_%s.txt" % name), "rb").read()
+    assert fg.stdout == want                             # banner, per-cycle S / SNRdb lines, "done"
+
+
+def test_vowel_stdout_banner(tmp_path):
+    c, fg, vw, g, o = _run("cfg4_lane2", tmp_path, 44)
+    assert vw.stdout.startswith(b"vowel /i/ MNV \nMaurilio N. Vieira, 28 mar 97. \n")
+    assert b"pre_emphasis= 1.00, gain=10.00, snr= 0.00\n" in vw.stdout

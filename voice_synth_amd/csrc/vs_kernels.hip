@@ -297,8 +297,17 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
         const double u = (1.0 * (double)r) / 2147483647.0;
         const int wv = vs_short_of(ceil(u * NDWd - half));
         if (act) wsum += (float)wv * (float)wv;
-        /* truncate((float)x[i] + w[i]) with x[i] == (short)DC on every noise position */
-        int xv = c.dcs + wv;
+        /* truncate((float)x[i] + w[i]).  x[i] is (short)DC on [T3,T) by construction and, for a
+         * monotone rising flank, on [0,T4) too -- but an amplitude above 32767 wraps the
+         * (short) conversion and leaves genuine pulse samples below T4, so those are read
+         * back from the ring (T4 == 0 in the usual configurations: branch not taken) */
+        int base = c.dcs;
+        if (__any(act && (q < T4))) {
+          int slot = s.wpos + i;
+          if (slot >= C) slot -= C;
+          if (act && (q < T4) && (i < T) && (i < room)) base = (int)ring[slot * VS_WAVE + lane];
+        }
+        int xv = base + wv;
         xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
         vs_emit(ring, C, lane, s, i, xv, act && (i < T) && (i < room));
       }
