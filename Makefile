@@ -54,4 +54,11 @@ clean:
 	rm -f $(CSRC)/*.o $(LIB) $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel
 	$(MAKE) -C oracle clean
 
-.PHONY: all clis oracle resources clean
+.PHONY: all clis oracle resources clean diag
+
+# diagnostic build with s_memtime stamps (never shipped, never timed): tools/diag_bench.py
+diag: $(LIBDIR)/libvoicesynth_diag.so
+$(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
+$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_api.o $(CSRC)/vs_host.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm

@@ -175,7 +175,7 @@ def test_expand_lane_matches_reference_expressions():
 
 def test_ring_slots():
     s = C.c_int()
-    assert vs.load().vs_ring_slots_for(159, C.byref(s)) == 0 and s.value >= 24 + 159 and s.value % 8 == 0
+    assert vs.load().vs_ring_slots_for(159, C.byref(s)) == 0 and s.value >= 24 + 159 and s.value % 24 == 0
     assert vs.load().vs_ring_slots_for(5000, C.byref(s)) == _ffi.VS_ERR_UNSUPPORTED
 
 

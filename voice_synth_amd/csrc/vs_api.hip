@@ -46,9 +46,11 @@ struct vs_plan {
   VsDevLane *d_lanes;
   double *d_costab;
   int ring_slots;
+  int ready_min;
   int ltab_entries;
   size_t lds_bytes;
   unsigned grid;
+  unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
 };
 
 #define VS_HIP(ctx, call)                        \
@@ -198,24 +200,42 @@ extern "C" void vs_cos_row(int T2, double *row)
   for (int k = 0; k < T2; k++) row[k] = cos(4.0 * atan(1.0) * k / T2);
 }
 
-/* Ring capacity in samples per lane.  A lane joins a generator round when its next cycle is
- * certain to fit (fill + tbound <= slots) and runs a filter super-step when it holds VS_SS
- * samples, so VS_SS - 1 + max(tbound) is the minimum; lanes with short periods get room for
- * several cycles per round (floor of VS_RING_MIN slots). */
-extern "C" int vs_ring_slots_for(int tmax, int *slots)
+/* Ring capacity in samples per lane and the super-step threshold that goes with it.
+ *
+ * A lane joins a generator round when its next cycle is certain to fit (fill + tbound <= slots)
+ * and takes part in a filter super-step when it holds VS_SS samples, so VS_SS + max(tbound) is
+ * the minimum.  More room lets lanes with long periods sit rounds out while the others catch
+ * up, which keeps both the rounds and the super-steps well attended; the policy table below
+ * comes from replaying real period sequences through the scheduler.
+ * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
+extern "C" int vs_ring_policy(int tmax, int *slots, int *ready_min)
 {
-  const int limit = (VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2); /* leave room for the cos rows */
-  int need = VS_SS + tmax;
-  if (need > limit) return VS_ERR_UNSUPPORTED;
-  int floor_slots = 192;
-  const char *env = getenv("VS_RING_MIN"); /* tuning knob for experiments */
-  if (env && *env) floor_slots = atoi(env);
-  int c = need > floor_slots ? need : floor_slots;
-  c = (c + 7) & ~7;
-  if (c > limit) c = limit;
+  const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
+  const int need = ((VS_SS + tmax + VS_SS - 1) / VS_SS) * VS_SS;
+  if (need > hard_limit) return VS_ERR_UNSUPPORTED;
+  int cap = 312; /* (312 + 1) rows * 128 B = 39.1 KiB: four workgroups per CU */
+  const char *env = getenv("VS_RING_SLOTS"); /* tuning knob for experiments */
+  if (env && *env) cap = (atoi(env) / VS_SS) * VS_SS;
+  if (cap > hard_limit) cap = hard_limit;
+  int want = ((VS_SS + (int)(1.7 * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
+  if (want < 192) want = 192;
+  int c = want < cap ? want : cap;
+  if (c < need) c = need;
+  const double rho = (double)(c - VS_SS) / (double)tmax;
+  int thr = 32;                 /* half the live lanes */
+  if (rho >= 1.65) thr = 64;    /* all of them */
+  else if (rho >= 1.45) thr = 58;
+  else if (rho >= 1.33) thr = 48;
+  env = getenv("VS_READY_MIN");
+  if (env && *env) thr = atoi(env);
+  if (thr < 1) thr = 1;
+  if (thr > 64) thr = 64;
   *slots = c;
+  if (ready_min) *ready_min = thr;
   return VS_OK;
 }
+
+extern "C" int vs_ring_slots_for(int tmax, int *slots) { return vs_ring_policy(tmax, slots, nullptr); }
 
 extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                               vs_plan **out)
@@ -248,8 +268,8 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     }
     if (dl[l].tbound > tmax) tmax = dl[l].tbound;
   }
-  int slots = 0;
-  int rc = vs_ring_slots_for(tmax, &slots);
+  int slots = 0, ready_min = 32;
+  int rc = vs_ring_policy(tmax, &slots, &ready_min);
   if (rc != VS_OK) return rc;
   /* cos rows staged per wavefront: sum of the distinct T2 among its 64 lanes, worst wavefront */
   int ltab_entries = 0;
@@ -266,7 +286,7 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     if (sum > ltab_entries) ltab_entries = sum;
   }
   ltab_entries = (ltab_entries + 1) & ~1;
-  if ((size_t)slots * VS_WAVE * 2 + (size_t)ltab_entries * 8 > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
+  if ((size_t)(slots + 1) * VS_WAVE * 2 + (size_t)ltab_entries * 8 > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
 
   vs_plan *p = new (std::nothrow) vs_plan();
   if (!p) return VS_ERR_NOMEM;
@@ -276,9 +296,12 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->d_lanes = nullptr;
   p->d_costab = nullptr;
   p->ring_slots = slots;
+  p->ready_min = ready_min;
   p->ltab_entries = ltab_entries;
-  p->lds_bytes = (size_t)slots * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+  /* ring rows + one trash row (lanes that must not emit write there) + the cos rows */
+  p->lds_bytes = (size_t)(slots + 1) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
   p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
+  p->d_diag = nullptr;
 
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
@@ -308,6 +331,14 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_lanes) (void)hipFree(p->d_lanes);
   if (p->d_costab) (void)hipFree(p->d_costab);
   delete p;
+}
+
+/* diagnostic builds (tools/diag_bench.py): device buffer of grid*8 uint64 cycle counters */
+extern "C" int vs_plan_set_diag(vs_plan *p, void *diag_dev)
+{
+  if (!p) return VS_ERR_ARG;
+  p->d_diag = (unsigned long long *)diag_dev;
+  return VS_OK;
 }
 
 extern "C" int vs_plan_info(const vs_plan *p, size_t *lds_bytes, size_t *n_workgroups,
@@ -345,6 +376,8 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.n_samples = (int)p->n_samples;
   a.ring_slots = p->ring_slots;
   a.ltab_entries = p->ltab_entries;
+  a.ready_min = p->ready_min;
+  a.diag = p->d_diag;
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);

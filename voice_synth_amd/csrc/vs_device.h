@@ -49,6 +49,8 @@ typedef struct VsKernelArgs {
   int ring_slots;
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
+  int ready_min;      /* super-step threshold: ready lanes * 64 >= live lanes * ready_min */
+  unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;
 
 #endif

@@ -42,6 +42,29 @@
 
 typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 
+/* Diagnostic build only (-DVS_DIAG, tools/diag_bench.py): s_memtime stamps at phase boundaries,
+ * summed per wavefront into args.diag.  The shipped library is built without it. */
+struct VsDiag {
+  unsigned long long acc[8];
+  unsigned long long t;
+};
+#ifdef VS_DIAG
+__device__ __forceinline__ unsigned long long vs_stamp()
+{
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define VS_DIAG_ADD(dg, k)                     \
+  {                                            \
+    const unsigned long long tn_ = vs_stamp(); \
+    (dg).acc[k] += tn_ - (dg).t;               \
+    (dg).t = tn_;                              \
+  }
+#else
+#define VS_DIAG_ADD(dg, k)
+#endif
+
 /* Philox4x32-10 (Salmon et al., SC'11), counter = (blk, 0, 0, 0). */
 __device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1, uint32_t &o0,
                                           uint32_t &o1, uint32_t &o2, uint32_t &o3)
@@ -100,6 +123,21 @@ __device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, bool activ
   return v >> 1;
 }
 
+/* (1.0*random())/RAND_MAX of flowgen_shimmer.c:325,387,398 for a draw r in [0, 2^31): the
+ * correctly rounded quotient r / 2147483647 from one multiply and two fused multiply-adds
+ * (Markstein's final-step form: q0 = r*inv is within one ulp, the residual r - q0*d is exact,
+ * inv = RN(1/d)).  Equality with IEEE division is verified EXHAUSTIVELY over all 2^31 draws,
+ * on the CPU by tests/test_div_shortcut.py and on the device by vs_ctx_selftest(). */
+__device__ __forceinline__ double vs_unit_of_draw(uint32_t r)
+{
+  const double d = 2147483647.0;
+  const double inv = 0x1.00000002p-31;
+  const double x = (double)r;
+  const double q0 = x * inv;
+  const double e = __builtin_fma(-q0, d, x);
+  return __builtin_fma(e, inv, q0);
+}
+
 /* (signed short) of a double, as gcc/x86-64 converts it: through int32, low 16 bits */
 __device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int)v; }
 
@@ -126,12 +164,13 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
   return s;
 }
 
-__device__ __forceinline__ void vs_emit(int16_t *ring, int C, int lane, const VsGen &s, int i,
-                                        int v, bool ok)
+/* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
+ * at most once, at i == thr (= C - wpos).  Lanes that must not emit write to a per-lane trash
+ * slot (row C of the ring) instead, so the generator loops stay free of exec-mask branches. */
+__device__ __forceinline__ int vs_ring_index(int wpos, int thr, int C, int i, int lane, bool ok)
 {
-  int slot = s.wpos + i;
-  if (slot >= C) slot -= C;
-  if (ok) ring[slot * VS_WAVE + lane] = (int16_t)v;
+  const int slot = wpos + i - ((i >= thr) ? C : 0);
+  return (ok ? slot : C) * VS_WAVE + lane;
 }
 
 /*
@@ -143,8 +182,9 @@ __device__ __forceinline__ void vs_emit(int16_t *ring, int C, int lane, const Vs
 template <bool LOG>
 __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int16_t *ring, int C,
                                                   int lane, int N, bool want, const double *ltab,
-                                                  vs_cycle_rec *logrow, int log_cap)
+                                                  vs_cycle_rec *logrow, int log_cap, VsDiag &dg)
 {
+  VS_DIAG_ADD(dg, 7)
   /* ---- jitter: fg:248-291 ---- */
   {
     const bool on = want && (c.flags & VS_DF_JITTER);
@@ -192,6 +232,7 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
     }
   }
 
+  VS_DIAG_ADD(dg, 0)
   const int T = s.T;
   const int T2 = c.T2;
   const int room = N - s.g; /* samples of this cycle that still belong to the utterance */
@@ -199,7 +240,12 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   const double *trow = ltab + c.tab_off;
   float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
 
-  /* ---- rising half-pulse: fg:318-324 (four samples per trip so the LDS reads overlap) ---- */
+  /* ---- rising half-pulse: fg:318-324.  Four samples per trip so the LDS reads overlap;
+   * everything is a select, not a branch (lanes differ in T2, T4 and their emit limit) ---- */
+  const double Ah = Ad * 0.5; /* "Amplitude * 0.5 * (...)" evaluates (Amplitude*0.5) first */
+  const float dcsf = (float)c.dcs;
+  const int lim = (T < room) ? T : room; /* samples of this cycle that are emitted */
+  const int wthr = C - s.wpos;
   for (int i0 = 0; __any(want && i0 < T2); i0 += 4) {
     double cs[4];
 #pragma unroll
@@ -208,23 +254,24 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k;
       const bool act = want && (i < T2);
-      int xs = vs_short_of(ceil(Ad * 0.5 * (1.0 - cs[k])));
-      if (act && ((float)xs < c.DC)) {
-        xs = c.dcs;
-        s.T4 = i;
-        psum = 0.0f;
-      }
-      if (act) psum += (float)xs * (float)xs;
-      vs_emit(ring, C, lane, s, i, xs, act && (i < T) && (i < room));
+      const int xs0 = vs_short_of(ceil(Ah * (1.0 - cs[k])));
+      const float xf0 = (float)xs0;
+      const bool lt = act && (xf0 < c.DC); /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
+      const int xs = lt ? c.dcs : xs0;
+      const float xf = lt ? dcsf : xf0;
+      s.T4 = lt ? i : s.T4;
+      const float pn = (lt ? 0.0f : psum) + xf * xf;
+      psum = act ? pn : psum;
+      ring[vs_ring_index(s.wpos, wthr, C, i, lane, act && (i < lim))] = (int16_t)xs;
     }
   }
 
+  VS_DIAG_ADD(dg, 1)
   /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
   float Knew;
   {
     const uint32_t r = vs_draw(c, s, want);
-    Knew = (float)((double)c.K *
-                   (1.0 + (double)(2.0f * c.Kvar) * (((1.0 * (double)r) / 2147483647.0) - 0.5)));
+    Knew = (float)((double)c.K * (1.0 + (double)(2.0f * c.Kvar) * (vs_unit_of_draw(r) - 0.5)));
   }
   const double Kd = (double)Knew;
 
@@ -241,27 +288,31 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
         const int i = T2 + k0 + k;
         const bool act = run && (k0 + k < T2);
         const int xs = vs_short_of(ceil(Ad * (Kd * cs[k] - Kd + 1.0)));
-        const bool brk = act && ((float)xs < c.DC);
-        if (brk) {
-          T3 = i;
-          run = false;
-        }
+        const float xf = (float)xs;
+        const bool brk = act && (xf < c.DC); /* if(x[i] < par.DC) break; */
+        T3 = brk ? i : T3;
+        run = run && !brk;
         const bool keep = act && !brk;
-        if (keep) psum += (float)xs * (float)xs;
-        vs_emit(ring, C, lane, s, i, xs, keep && (i < T) && (i < room));
+        psum = keep ? (psum + xf * xf) : psum;
+        ring[vs_ring_index(s.wpos, wthr, C, i, lane, keep && (i < lim))] = (int16_t)xs;
       }
     }
   }
 
+  VS_DIAG_ADD(dg, 2)
   float x_pow = 0.0f, w_pow = 0.0f;
   const bool noisy = want && (c.flags & VS_DF_NOISE);
 
   /* ---- closed phase without noise: fg:334-336 ---- */
-  for (int i = T3; __any(want && !noisy && i < T); ++i) {
-    const bool act = want && !noisy && (i < T);
-    vs_emit(ring, C, lane, s, i, c.dcs, act && (i < room));
+  for (int i0 = 0; __any(want && !noisy && (T3 + i0 < lim)); i0 += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = T3 + i0 + k;
+      ring[vs_ring_index(s.wpos, wthr, C, i, lane, want && !noisy && (i < lim))] = (int16_t)c.dcs;
+    }
   }
 
+  VS_DIAG_ADD(dg, 3)
   /* ---- closed phase with noise: fg:373-411 ---- */
   if (__any(noisy)) {
     x_pow = psum / ((float)T3 - (float)s.T4);
@@ -277,45 +328,81 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
     const uint32_t bfirst = d0 >> 2;
     const int nblk = (m > 0) ? (int)(((d0 + (uint32_t)m - 1u) >> 2) - bfirst) + 1 : 0;
     float wsum = 0.0f;
-    for (int bi = 0; __any(bi < nblk); ++bi) {
-      const bool bact = bi < nblk;
-      const uint32_t b = bfirst + (uint32_t)bi;
-      uint32_t o0, o1, o2, o3;
-      vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-      if (bact) {
-        s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
-        s.blk_idx = b;
-      }
+    if (!__any(noisy && (T4 > 0))) {
+      /* usual case (DC flow 0.25 after -n: T4 == 0): the draws map to i = T3 + q, q = 0..m-1 */
+      int mlim = lim - T3;
+      mlim = (mlim < m) ? mlim : m;
+      mlim = (mlim > 0) ? mlim : 0;
+      int slot0 = s.wpos + T3; /* ring slot of q == 0; T3 <= P + 2 < C */
+      if (slot0 >= C) slot0 -= C;
+      const int qthr = C - slot0;       /* first q whose slot wraps */
+      int q0 = (int)(4u * bfirst - d0); /* ordinal of word 0 of the first block, -3..0 */
+      for (int bi = 0; __any(bi < nblk); ++bi) {
+        const bool bact = bi < nblk;
+        const uint32_t b = bfirst + (uint32_t)bi;
+        uint32_t o0, o1, o2, o3;
+        vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
+        if (bact) {
+          s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
+          s.blk_idx = b;
+        }
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
-        const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
-        const bool act = bact && (q >= 0) && (q < m);
-        const int i = (q < T4) ? q : (T3 + (q - T4));
-        const uint32_t r = ow >> 1;
-        /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
-        const double u = (1.0 * (double)r) / 2147483647.0;
-        const int wv = vs_short_of(ceil(u * NDWd - half));
-        if (act) wsum += (float)wv * (float)wv;
-        /* truncate((float)x[i] + w[i]).  x[i] is (short)DC on [T3,T) by construction and, for a
-         * monotone rising flank, on [0,T4) too -- but an amplitude above 32767 wraps the
-         * (short) conversion and leaves genuine pulse samples below T4, so those are read
-         * back from the ring (T4 == 0 in the usual configurations: branch not taken) */
-        int base = c.dcs;
-        if (__any(act && (q < T4))) {
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
+          const int q = q0 + w;
+          const double u = vs_unit_of_draw(ow >> 1);
+          const int wv = vs_short_of(ceil(u * NDWd - half));
+          if (LOG) {
+            if (bact && ((unsigned)q < (unsigned)m)) wsum += (float)wv * (float)wv;
+          }
+          int xv = c.dcs + wv;
+          xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
+          const bool ok = bact && ((unsigned)q < (unsigned)mlim);
+          const int slot = slot0 + q - ((q >= qthr) ? C : 0);
+          ring[(ok ? slot : C) * VS_WAVE + lane] = (int16_t)xv;
+        }
+        q0 += 4;
+      }
+    } else {
+      /* general case: draws cover [0,T4) then [T3,T) */
+      for (int bi = 0; __any(bi < nblk); ++bi) {
+        const bool bact = bi < nblk;
+        const uint32_t b = bfirst + (uint32_t)bi;
+        uint32_t o0, o1, o2, o3;
+        vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
+        if (bact) {
+          s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
+          s.blk_idx = b;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
+          const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
+          const bool act = bact && (q >= 0) && (q < m);
+          const int i = (q < T4) ? q : (T3 + (q - T4));
+          /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
+          const double u = vs_unit_of_draw(ow >> 1);
+          const int wv = vs_short_of(ceil(u * NDWd - half));
+          if (act) wsum += (float)wv * (float)wv;
+          /* truncate((float)x[i] + w[i]).  x[i] is (short)DC on [T3,T) by construction and, for
+           * a monotone rising flank, on [0,T4) too -- but an amplitude above 32767 wraps the
+           * (short) conversion and leaves genuine pulse samples below T4, so those are read
+           * back from the ring */
           int slot = s.wpos + i;
           if (slot >= C) slot -= C;
-          if (act && (q < T4) && (i < T) && (i < room)) base = (int)ring[slot * VS_WAVE + lane];
+          int base = c.dcs;
+          if (act && (q < T4) && (i < lim)) base = (int)ring[slot * VS_WAVE + lane];
+          int xv = base + wv;
+          xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
+          if (act && (i < lim)) ring[slot * VS_WAVE + lane] = (int16_t)xv;
         }
-        int xv = base + wv;
-        xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-        vs_emit(ring, C, lane, s, i, xv, act && (i < T) && (i < room));
       }
     }
     if (noisy) s.d = d0 + (uint32_t)m;
     w_pow = wsum / (float)T;
   }
 
+  VS_DIAG_ADD(dg, 4)
   if (LOG) {
     if (want && logrow && s.cyc < log_cap) {
       vs_cycle_rec rec;
@@ -335,6 +422,7 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
     if (wp >= C) wp -= C;
     s.wpos = wp;
   }
+  VS_DIAG_ADD(dg, 5)
 }
 
 template <int ARITH, int KIND, bool LOG>
@@ -363,7 +451,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
   VsCfg c;
   VsGen s;
-  double *ltab = (double *)(ring + (size_t)C * VS_WAVE);
+  double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE); /* row C of the ring is the trash slot */
   if (KIND != VS_KIND_FILTER) {
     c.jitter = L->jitter; c.shimmer = L->shimmer; c.K = L->K; c.Kvar = L->Kvar;
     c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
@@ -404,21 +492,36 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   int16_t *__restrict__ orow = args.out + row * args.out_pitch;
   const int16_t *__restrict__ irow = (KIND == VS_KIND_FILTER) ? args.in + row * args.in_pitch : nullptr;
 
+  VsDiag dg;
+#ifdef VS_DIAG
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+  dg.t = vs_stamp();
+#endif
   int n = 0;     /* this lane's position in its own utterance */
   int rslot = 0; /* ring slot of sample n */
   bool live = valid;
+  /* Scheduling: a super-step costs the same whether 1 or 64 lanes take
+   * part, and so does a generator round.  Run a super-step when at least ready_min/64 of the
+   * live lanes hold 24 samples; otherwise let every lane with room produce its next cycle
+   * (the lanes that are short always have room).  Lanes whose periods run long fill their
+   * ring and sit rounds out -- they have fewer cycles to produce anyway. */
   while (__any(live)) {
-    /* ---- generator rounds: every lane whose next cycle is certain to fit produces it ---- */
+    bool ready = live;
     if (KIND != VS_KIND_FILTER) {
-      bool want = live && (s.g < N) && (s.g - n + c.tbound <= C);
-      while (__any(want)) {
-        vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, ltab, logrow, (int)args.log_pitch);
-        want = live && (s.g < N) && (s.g - n + c.tbound <= C);
+      ready = live && ((s.g - n >= VS_SS) || (s.g >= N));
+      const bool want = live && (s.g < N) && (s.g - n + c.tbound <= C);
+      const int n_live = __builtin_popcountll(__ballot(live));
+      const int n_ready = __builtin_popcountll(__ballot(ready));
+      const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * args.ready_min) || !__any(want));
+      if (!filter_now) {
+        vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, ltab, logrow, (int)args.log_pitch, dg);
+        continue;
       }
     }
 
     /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
-    while (live && ((KIND == VS_KIND_FILTER) || (s.g - n >= VS_SS) || (s.g >= N))) {
+    if (ready) {
       int xin[VS_SS];
       if (KIND == VS_KIND_FILTER) {
         if (args.vec_ok && (n + VS_SS <= N)) {
@@ -436,14 +539,13 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
           for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
         }
       } else {
+        /* ring_slots is a multiple of VS_SS and rslot advances by VS_SS from 0: a super-step
+         * never wraps, its 24 reads share one base address */
+        const int16_t *rp = ring + rslot * VS_WAVE + lane;
 #pragma unroll
-        for (int t = 0; t < VS_SS; ++t) {
-          int slot = rslot + t;
-          if (slot >= C) slot -= C;
-          xin[t] = (int)ring[slot * VS_WAVE + lane];
-        }
+        for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
         rslot += VS_SS;
-        if (rslot >= C) rslot -= C;
+        if (rslot >= C) rslot = 0;
       }
 
       /* 24 steps of the recurrence, vowel_new.c:266-289 */
@@ -500,7 +602,14 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
       n += VS_SS;
       if (n >= N) live = false;
     }
+    VS_DIAG_ADD(dg, 6)
   }
+#ifdef VS_DIAG
+  if (args.diag && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) args.diag[(size_t)blockIdx.x * 8 + k] = dg.acc[k];
+  }
+#endif
 
   if (KIND != VS_KIND_FILTER && args.ncyc && valid) args.ncyc[row] = s.cyc;
 }
