@@ -65,7 +65,7 @@ def cpu_baseline(specs_fn, n_samples, target_s):
     po.synth(lanes, n_samples, threads=cores)
     t_cal = time.perf_counter() - t0
     rate = lanes_cal * n_samples / t_cal
-    n_lanes = int(min(131072, max(lanes_cal, target_s * rate / n_samples)))
+    n_lanes = int(min(262144, max(lanes_cal, target_s * rate / n_samples)))
     n_lanes = (n_lanes // cores) * cores or cores
     lanes, _ = vs.lanes_from_specs(specs_fn(n_lanes))
     t0 = time.perf_counter()

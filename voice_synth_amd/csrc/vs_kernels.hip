@@ -141,16 +141,18 @@ __device__ __forceinline__ double vs_unit_of_draw(uint32_t r)
 /* (signed short) of a double, as gcc/x86-64 converts it: through int32, low 16 bits */
 __device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int)v; }
 
-/* vowel_new.c:413-427 */
+/* round2int() of vowel_new.c:413-427:
+ *     dec = x - floor(x); if (dec > 0.5) x = x + 1; clamp x to [-32767, 32767]; return floor(x)
+ * The "+1" stays a double addition (it is part of the reference's rounding sequence); the clamp
+ * moves behind the floor into integers, which gives the same result for every finite x:
+ * floor is monotone, floor(+-32767) = +-32767, and v_cvt_i32_f64 saturates beyond int32.  x is
+ * never NaN (stable filter, int16 input). */
 __device__ __forceinline__ int vs_round2int(double x)
 {
-  /* branch-free: "if (dec > 0.5) x = x + 1" adds 1.0 or nothing (x + 0.0 only turns -0.0 into
-   * +0.0, both floor to 0); the two-sided clamp is a min/max pair (x is never NaN: the filter
-   * is stable and its input is int16) */
   const double dec = x - floor(x);
-  x = x + ((dec > 0.5) ? 1.0 : 0.0);
-  x = (x > 32767.0) ? 32767.0 : ((x < -32767.0) ? -32767.0 : x);
-  return (int)floor(x);
+  x = x + ((dec > 0.5) ? 1.0 : 0.0); /* x + 0.0 only turns -0.0 into +0.0; both floor to 0 */
+  const int v = (int)floor(x);
+  return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
 }
 
 /* (int)sqrt(v) of the reference (flowgen_shimmer.c:382) for a float-valued v >= 0: the
