@@ -41,6 +41,7 @@ extern "C" {
 #define VS_ERR_NODEVICE (-6)     /* no usable gfx950 device: there is no CPU path */
 #define VS_ERR_IO (-7)
 #define VS_USAGE (-8)            /* argv parsers: the reference would print usage() and exit(0) */
+#define VS_ERR_INTERNAL (-9)     /* a device-side bounded wait ran out (kernel bug, never expected) */
 
 /* vs_lane.flags: which perturbation options were GIVEN on the command line.  The reference
  * tests "arg.X != -1" (flowgen_shimmer.c:248, 295, 373), not only the value. */
@@ -181,6 +182,10 @@ int vs_plan_launch(vs_plan *plan, int kind, const int16_t *in_dev, size_t in_pit
                    int16_t *out_dev, size_t out_pitch, vs_cycle_rec *log_dev, size_t log_pitch,
                    int32_t *ncyc_dev);
 int vs_ctx_synchronize(vs_ctx *ctx);
+/* Waits for the context's stream, then reports the health word of the plan's launches:
+ * VS_OK, or VS_ERR_INTERNAL if a device-side bounded wait ran out (*flags, optional, gets the
+ * raw bits).  The one-call conveniences below check it themselves. */
+int vs_plan_status(vs_plan *plan, int *flags);
 
 /* Dynamic LDS bytes per 64-lane workgroup and launch geometry a plan will use. */
 int vs_plan_info(const vs_plan *plan, size_t *lds_bytes, size_t *n_workgroups,

@@ -77,3 +77,17 @@ def test_cycle_log_matches_oracle(engine):
         assert np.array_equal(f, flow[l])
         for name in ("S", "x_pow", "w_pow", "T"):
             assert np.array_equal(recs[l][:n][name], r[name]), name
+
+
+def test_experimental_wave_specialised_kernel_bit_exact(monkeypatch):
+    """VS_KERNEL=ws: generator wave + filter wave per 64 utterances, coupled through LDS
+    progress words (kept as an opt-in experiment)."""
+    monkeypatch.setenv("VS_KERNEL", "ws")
+    eng = vs.Engine(0)
+    try:
+        for index, n in ((3, 200), (5, 130), (4, 70)):
+            lanes, ns = _lanes(index, n)
+            got = eng.synth(lanes, ns)          # vs_synth checks the kernel's spin-limit word
+            assert np.array_equal(got, po.synth(lanes, ns)), index
+    finally:
+        eng.close()

@@ -1,0 +1,29 @@
+"""Phase breakdown of the WAVE-SPECIALISED fused kernel from the diagnostic build."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import voice_synth_amd._ffi as ffi
+ffi.LIB_PATH = os.path.join(os.path.dirname(ffi.LIB_PATH), "libvoicesynth_diag.so")
+import voice_synth_amd as vs
+from voice_synth_amd import configs
+GN = ["jitter+shimmer", "rising", "Knew+falling", "closed", "noise", "bookkeeping", "sleep/poll", "loop ctl"]
+FN = ["superstep+publish", "-", "-", "-", "-", "-", "sleep/poll", "poll+decide"]
+def main():
+    n = 65536
+    specs, fs, dur, label = configs.config_specs(3, n)
+    lanes, d = vs.lanes_from_specs(specs); ns = vs.num_samples(fs, d)
+    eng = vs.Engine(0); lib = vs.load()
+    lib.vs_plan_set_diag.restype = C.c_int; lib.vs_plan_set_diag.argtypes = [C.c_void_p, C.c_void_p]
+    plan = eng.plan(lanes, ns); grid = plan.info()["workgroups"]
+    out = eng.dev_alloc(n * ns * 2); dg = eng.dev_alloc(grid * 16 * 8)
+    lib.vs_plan_set_diag(plan._plan, C.c_void_p(dg))
+    for _ in range(2):
+        plan.launch(vs.VS_KIND_SYNTH, out); eng.synchronize()
+    a = eng.dev_download(dg, (grid, 16), np.uint64).astype(np.float64)
+    for w, names in ((0, GN), (1, FN)):
+        part = a[:, 8 * w:8 * w + 8]; tot = part.sum(axis=1).mean()
+        print("wave %d (%s): ticks per sample %.0f" % (w, "generator" if w == 0 else "filter", tot / ns))
+        for k in range(8):
+            if names[k] != "-":
+                print("    %-18s %7.1f ticks/sample" % (names[k], part[:, k].mean() / ns))
+main()

@@ -256,6 +256,12 @@ class Plan:
             "vs_plan_launch",
         )
 
+    def status(self):
+        """Waits for the stream; raises VsError(VS_ERR_INTERNAL) if a device-side wait ran out."""
+        flags = C.c_int()
+        check(self._lib.vs_plan_status(self._plan, C.byref(flags)), "vs_plan_status")
+        return flags.value
+
     def close(self):
         if self._plan:
             self._lib.vs_plan_destroy(self._plan)

@@ -23,6 +23,7 @@ VS_ERR_NOMEM = -5
 VS_ERR_NODEVICE = -6
 VS_ERR_IO = -7
 VS_USAGE = -8
+VS_ERR_INTERNAL = -9
 
 VS_FLAG_JITTER = 0x1
 VS_FLAG_SHIMMER = 0x2
@@ -144,6 +145,7 @@ SYMBOLS = {
         [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp],
     ),
     "vs_ctx_synchronize": (C.c_int, [_vp]),
+    "vs_plan_status": (C.c_int, [_vp, _P(C.c_int)]),
     "vs_plan_info": (C.c_int, [_vp, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t)]),
     "vs_synth": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp]),
     "vs_source": (

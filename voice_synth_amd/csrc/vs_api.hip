@@ -26,8 +26,9 @@
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
 
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, const VsKernelArgs *args,
-                                       unsigned grid, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
+                                       const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
+                                       hipStream_t stream);
 
 #define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
 
@@ -51,6 +52,8 @@ struct vs_plan {
   size_t lds_bytes;
   unsigned grid;
   unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
+  int *d_err;                 /* spin-limit word of the wave-specialised kernel */
+  int wave_specialised;
 };
 
 #define VS_HIP(ctx, call)                        \
@@ -213,7 +216,7 @@ extern "C" int vs_ring_policy(int tmax, int *slots, int *ready_min)
   const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
   const int need = ((VS_SS + tmax + VS_SS - 1) / VS_SS) * VS_SS;
   if (need > hard_limit) return VS_ERR_UNSUPPORTED;
-  int cap = 312; /* (312 + 1) rows * 128 B = 39.1 KiB: four workgroups per CU */
+  int cap = 288; /* (288 + 1) rows * 128 B = 36.1 KiB + cos rows + sync words: four workgroups per CU */
   const char *env = getenv("VS_RING_SLOTS"); /* tuning knob for experiments */
   if (env && *env) cap = (atoi(env) / VS_SS) * VS_SS;
   if (cap > hard_limit) cap = hard_limit;
@@ -302,10 +305,20 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->lds_bytes = (size_t)(slots + 1) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
   p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
   p->d_diag = nullptr;
+  p->d_err = nullptr;
+  {
+    /* VS_KERNEL=ws selects the experimental wave-specialised fused kernel (generator wave +
+     * filter wave per 64 utterances).  It is bit-exact but SLOWER at the LDS capacity that keeps
+     * four workgroups per CU, so the one-wave kernel is the default. */
+    const char *k = getenv("VS_KERNEL");
+    p->wave_specialised = (k && strcmp(k, "ws") == 0);
+  }
 
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, costab.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), ctx->stream);
   if (e == hipSuccess)
     e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
                        ctx->stream);
@@ -317,6 +330,7 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     ctx->last_hip_error = (int)e;
     if (p->d_lanes) (void)hipFree(p->d_lanes);
     if (p->d_costab) (void)hipFree(p->d_costab);
+    if (p->d_err) (void)hipFree(p->d_err);
     delete p;
     return VS_ERR_HIP;
   }
@@ -330,7 +344,20 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   (void)hipSetDevice(p->ctx->device);
   if (p->d_lanes) (void)hipFree(p->d_lanes);
   if (p->d_costab) (void)hipFree(p->d_costab);
+  if (p->d_err) (void)hipFree(p->d_err);
   delete p;
+}
+
+extern "C" int vs_plan_status(vs_plan *p, int *flags)
+{
+  if (!p) return VS_ERR_ARG;
+  vs_ctx *ctx = p->ctx;
+  int word = 0;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipMemcpyAsync(&word, p->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (flags) *flags = word;
+  return word ? VS_ERR_INTERNAL : VS_OK;
 }
 
 /* diagnostic builds (tools/diag_bench.py): device buffer of grid*8 uint64 cycle counters */
@@ -378,13 +405,19 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.ltab_entries = p->ltab_entries;
   a.ready_min = p->ready_min;
   a.diag = p->d_diag;
+  a.err = p->d_err;
+  a.gen_min = 32;
+  {
+    const char *gm = getenv("VS_GEN_MIN"); /* tuning knob for experiments */
+    if (gm && *gm) a.gen_min = atoi(gm);
+  }
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);
   a.vec_ok = vec;
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr, &a, p->grid, p->lds_bytes,
-                               ctx->stream));
+  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr, p->wave_specialised != 0, &a,
+                               p->grid, p->lds_bytes, ctx->stream));
   return VS_OK;
 }
 
@@ -430,6 +463,7 @@ static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lan
       e = hipMemcpyAsync(ncyc, d_ncyc, n_lanes * sizeof(int32_t), hipMemcpyDeviceToHost,
                          ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && rc == VS_OK) rc = vs_plan_status(plan, nullptr);
   }
   if (d_out) (void)hipFree(d_out);
   if (d_in) (void)hipFree(d_in);

@@ -50,6 +50,8 @@ typedef struct VsKernelArgs {
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
   int ready_min;      /* super-step threshold: ready lanes * 64 >= live lanes * ready_min */
+  int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
+  int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;
 

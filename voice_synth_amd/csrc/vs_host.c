@@ -31,6 +31,7 @@ const char *vs_strerror(int code)
     case VS_ERR_NODEVICE: return "no usable gfx950 device (there is no CPU path)";
     case VS_ERR_IO: return "I/O error";
     case VS_USAGE: return "usage";
+    case VS_ERR_INTERNAL: return "device-side wait ran out (internal error)";
     default: return "unknown error";
   }
 }

@@ -427,6 +427,131 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   VS_DIAG_ADD(dg, 5)
 }
 
+/*
+ * One filter super-step of one lane: 24 samples of vowel_new.c:266-289 starting at the lane's
+ * own position n.  x comes from the lane's ring column (rp = &ring[rslot][lane], never wraps
+ * inside a super-step because ring_slots is a multiple of VS_SS and rslot advances by VS_SS
+ * from 0) or, for VS_KIND_FILTER, from HBM.  The 24 int16 results leave as three 16-byte
+ * stores.  y[] is the rotating window of the last 24 outputs in double (y[t] = y at n+t-24
+ * on entry, = y at n+t on exit).
+ */
+template <int ARITH, int KIND>
+__device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
+                                             double gain, double pre, const int16_t *rp,
+                                             const int16_t *__restrict__ irow,
+                                             int16_t *__restrict__ orow, int n, int N, bool vec_ok)
+{
+  int xin[VS_SS];
+  if (KIND == VS_KIND_FILTER) {
+    if (vec_ok && (n + VS_SS <= N)) {
+#pragma unroll
+      for (int k = 0; k < VS_SS / 8; ++k) {
+        const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+          xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+  }
+
+  int outv[VS_SS];
+  if (KIND == VS_KIND_SOURCE) {
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t) {
+      /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
+      double acc = (double)xin[t] * gain;
+      const double y1 = y[(t + VS_SS - 1) % VS_SS];
+      if (ARITH == VS_ARITH_EXACT) {
+        /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
+         * difference rounded on its own */
+#pragma unroll
+        for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
+      } else {
+        /* four partial sums over the older taps, the newest tap (j = 1) last */
+        double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+        for (int j = 2; j <= VS_ORDER; ++j) {
+          const double yj = y[(t + VS_SS - j) % VS_SS];
+          if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
+          else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
+          else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
+          else p3 = __builtin_fma(-a[j], yj, p3);
+        }
+        acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
+      }
+      /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
+      const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
+      outv[t] = vs_round2int(o);
+      y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+    }
+  }
+
+  if (vec_ok && (n + VS_SS <= N)) {
+#pragma unroll
+    for (int k = 0; k < VS_SS / 8; ++k) {
+      vs_u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
+      *(vs_u32x4 *)(orow + n + 8 * k) = v;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t)
+      if (n + t < N) orow[n + t] = (int16_t)outv[t];
+  }
+}
+
+/* per-lane constants of the generator from the lane record */
+__device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsCfg &c, VsGen &s)
+{
+  c.jitter = L->jitter; c.shimmer = L->shimmer; c.K = L->K; c.Kvar = L->Kvar;
+  c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
+  c.a_hi = L->a_hi; c.a_lo = L->a_lo;
+  c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = 0;
+  c.tbound = L->tbound; c.dcs = L->dcs;
+  c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
+  s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
+  s.dp0 = 0.0f; s.ds0 = 0.0f;
+  s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
+}
+
+/* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its lanes
+ * (one pass for a homogeneous batch).  The host sized the region for the worst wavefront of
+ * the plan (ltab_entries).  Sets c.tab_off. */
+__device__ __forceinline__ void vs_stage_cos_rows(const VsDevLane *__restrict__ L, VsCfg &c,
+                                                  double *ltab, const double *__restrict__ costab,
+                                                  int ltab_entries, int lane, bool valid)
+{
+  const int gtab = L->tab_off;
+  int used = 0;
+  bool pending = valid;
+  while (__any(pending)) {
+    const unsigned long long m = __ballot(pending);
+    const int leader = __builtin_ctzll(m);
+    const int T2s = __builtin_amdgcn_readlane(c.T2, leader);
+    const int gs = __builtin_amdgcn_readlane(gtab, leader);
+    if (used + T2s > ltab_entries) __builtin_trap(); /* plan and kernel disagree */
+    for (int k = lane; k < T2s; k += VS_WAVE) ltab[used + k] = costab[gs + k];
+    if (pending && c.T2 == T2s) {
+      c.tab_off = used;
+      pending = false;
+    }
+    used += T2s;
+  }
+}
+
 template <int ARITH, int KIND, bool LOG>
 __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 {
@@ -455,37 +580,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   VsGen s;
   double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE); /* row C of the ring is the trash slot */
   if (KIND != VS_KIND_FILTER) {
-    c.jitter = L->jitter; c.shimmer = L->shimmer; c.K = L->K; c.Kvar = L->Kvar;
-    c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
-    c.a_hi = L->a_hi; c.a_lo = L->a_lo;
-    c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = 0;
-    c.tbound = L->tbound; c.dcs = L->dcs;
-    c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
-    s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
-    s.dp0 = 0.0f; s.ds0 = 0.0f;
-    s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
-
-    /* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its
-     * lanes (one pass for a homogeneous batch).  The host sized the region for the worst
-     * wavefront of the plan (args.ltab_entries). */
-    {
-      const int gtab = L->tab_off;
-      int used = 0;
-      bool pending = valid;
-      while (__any(pending)) {
-        const unsigned long long m = __ballot(pending);
-        const int leader = __builtin_ctzll(m);
-        const int T2s = __builtin_amdgcn_readlane(c.T2, leader);
-        const int gs = __builtin_amdgcn_readlane(gtab, leader);
-        if (used + T2s > args.ltab_entries) __builtin_trap(); /* plan and kernel disagree */
-        for (int k = lane; k < T2s; k += VS_WAVE) ltab[used + k] = args.costab[gs + k];
-        if (pending && c.T2 == T2s) {
-          c.tab_off = used;
-          pending = false;
-        }
-        used += T2s;
-      }
-    }
+    vs_load_cfg(L, c, s);
+    vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
     __syncthreads(); /* single-wave workgroup: orders the staging writes before the row reads */
   }
   vs_cycle_rec *logrow = nullptr;
@@ -524,82 +620,11 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
     /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
     if (ready) {
-      int xin[VS_SS];
-      if (KIND == VS_KIND_FILTER) {
-        if (args.vec_ok && (n + VS_SS <= N)) {
-#pragma unroll
-          for (int k = 0; k < VS_SS / 8; ++k) {
-            const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
-              xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
-        }
-      } else {
-        /* ring_slots is a multiple of VS_SS and rslot advances by VS_SS from 0: a super-step
-         * never wraps, its 24 reads share one base address */
-        const int16_t *rp = ring + rslot * VS_WAVE + lane;
-#pragma unroll
-        for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+      vs_superstep<ARITH, KIND>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
+                                args.vec_ok != 0);
+      if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
         if (rslot >= C) rslot = 0;
-      }
-
-      /* 24 steps of the recurrence, vowel_new.c:266-289 */
-      int outv[VS_SS];
-      if (KIND == VS_KIND_SOURCE) {
-#pragma unroll
-        for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
-      } else {
-#pragma unroll
-        for (int t = 0; t < VS_SS; ++t) {
-          /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-          double acc = (double)xin[t] * gain;
-          const double y1 = y[(t + VS_SS - 1) % VS_SS];
-          if (ARITH == VS_ARITH_EXACT) {
-            /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
-             * difference rounded on its own */
-#pragma unroll
-            for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
-          } else {
-            /* four partial sums over the older taps, the newest tap (j = 1) last */
-            double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-#pragma unroll
-            for (int j = 2; j <= VS_ORDER; ++j) {
-              const double yj = y[(t + VS_SS - j) % VS_SS];
-              if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
-              else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
-              else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
-              else p3 = __builtin_fma(-a[j], yj, p3);
-            }
-            acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
-          }
-          /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
-          const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
-          outv[t] = vs_round2int(o);
-          y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
-        }
-      }
-
-      /* 24 int16 results: three 16-byte stores per lane */
-      if (args.vec_ok && (n + VS_SS <= N)) {
-#pragma unroll
-        for (int k = 0; k < VS_SS / 8; ++k) {
-          vs_u32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
-          *(vs_u32x4 *)(orow + n + 8 * k) = v;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < VS_SS; ++t)
-          if (n + t < N) orow[n + t] = (int16_t)outv[t];
       }
       n += VS_SS;
       if (n >= N) live = false;
@@ -616,6 +641,155 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   if (KIND != VS_KIND_FILTER && args.ncyc && valid) args.ncyc[row] = s.cyc;
 }
 
+/*
+ * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts of one
+ * 128-thread workgroup -- wave 0 only generates (vs_generate_cycle), wave 1 only filters
+ * (vs_superstep) -- coupled through the LDS ring and two per-lane progress words.
+ *
+ * Why: at batch 65536 the one-wave kernel leaves exactly one wavefront per SIMD, and one
+ * wavefront can issue a VALU instruction only every ~4 cycles (tools/ubench: an fp64
+ * instruction costs 5.3 ticks with one wave per SIMD, 3.6 with two; an integer one 5.3 vs
+ * 2.7) and exposes every LDS / dependency stall.  Two waves per 64 utterances put two waves
+ * on every SIMD without needing more utterances.
+ *
+ * Hand-off (workgroup scope, LDS only):
+ *   gpub[l] = samples lane l's generator has written to the ring   (written by wave 0)
+ *   npub[l] = samples lane l's filter has read from the ring        (written by wave 1)
+ * The LDS executes one wavefront's operations in order, so "ring writes, then gpub" on one
+ * side and "gpub read, then ring reads" on the other is a release/acquire pair; the fences
+ * below keep the compiler from reordering.  Wave 0 writes slots of [g, g+T) only when
+ * g - npub + tbound <= C, i.e. never over samples the filter has not consumed.
+ *
+ * Progress: a lane that is short of 24 samples always has room for its next cycle, and wave 0
+ * generates whenever such a lane exists; if no lane has room every lane holds more than 24
+ * samples and wave 1 runs.  Spins are bounded (VS_SPIN_LIMIT polls, then the error word of
+ * the launch is set and the wave leaves) so that a protocol bug cannot hang the device.
+ */
+#define VS_SPIN_LIMIT (1 << 22)
+
+template <int ARITH>
+__global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) int16_t ring[];
+
+  const int wave = (int)threadIdx.x >> 6;
+  const int lane = (int)threadIdx.x & (VS_WAVE - 1);
+  const long gl = (long)blockIdx.x * VS_WAVE + lane;
+  const bool valid = gl < (long)args.n_lanes;
+  const VsDevLane *__restrict__ L = args.lanes + (valid ? gl : (long)args.n_lanes - 1);
+  const int N = args.n_samples;
+  const int C = args.ring_slots;
+  double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE);
+  int *gpub = (int *)(ltab + args.ltab_entries);
+  int *npub = gpub + VS_WAVE;
+  const long row = (long)L->row;
+
+  if (wave == 0) gpub[lane] = 0;
+  else npub[lane] = 0;
+  __syncthreads();
+
+  if (wave == 0) {
+    /* ------------------------------- generator wave ------------------------------- */
+    VsCfg c;
+    VsGen s;
+    VsDiag dg;
+#ifdef VS_DIAG
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+    dg.t = vs_stamp();
+#endif
+    vs_load_cfg(L, c, s);
+    vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
+    int spins = 0;
+    for (;;) {
+      const bool need = valid && (s.g < N);
+      if (!__any(need)) break;
+      const int n_seen = __hip_atomic_load(&npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const bool want = need && (s.g - n_seen + c.tbound <= C);
+      const bool hungry = want && (s.g - n_seen < 2 * VS_SS); /* its filter is about to run dry */
+      const int n_need = __builtin_popcountll(__ballot(need));
+      const int n_want = __builtin_popcountll(__ballot(want));
+      if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
+        vs_generate_cycle<false>(c, s, ring, C, lane, N, want, ltab, nullptr, 0, dg);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        spins = 0;
+      } else {
+        __builtin_amdgcn_s_sleep(2);
+        VS_DIAG_ADD(dg, 6)
+        if (++spins > VS_SPIN_LIMIT) {
+          if (args.err && lane == 0) atomicOr(args.err, 1);
+          break;
+        }
+      }
+    }
+#ifdef VS_DIAG
+    if (args.diag && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) args.diag[(size_t)blockIdx.x * 16 + k] = dg.acc[k];
+    }
+#endif
+    if (args.ncyc && valid) args.ncyc[row] = s.cyc;
+  } else {
+    /* --------------------------------- filter wave --------------------------------- */
+    double a[VS_ORDER + 1];
+    double y[VS_SS];
+    a[0] = 1.0;
+#pragma unroll
+    for (int j = 1; j <= VS_ORDER; ++j) a[j] = L->a[j - 1];
+#pragma unroll
+    for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
+    const double gain = L->gain;
+    const double pre = L->pre;
+    int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+    int n = 0, rslot = 0, spins = 0;
+    bool live = valid;
+    VsDiag dg;
+#ifdef VS_DIAG
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+    dg.t = vs_stamp();
+#endif
+    while (__any(live)) {
+      VS_DIAG_ADD(dg, 7)
+      const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const bool ready = live && ((g_seen - n >= VS_SS) || (g_seen >= N));
+      const int n_live = __builtin_popcountll(__ballot(live));
+      const int n_ready = __builtin_popcountll(__ballot(ready));
+      if ((n_ready > 0) && (n_ready * 64 >= n_live * args.ready_min)) {
+        if (ready) {
+          vs_superstep<ARITH, VS_KIND_SYNTH>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
+                                             orow, n, N, args.vec_ok != 0);
+          rslot += VS_SS;
+          if (rslot >= C) rslot = 0;
+          n += VS_SS;
+          if (n >= N) live = false;
+        }
+        /* the ring reads above precede this store in the LDS queue: the slots are free */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&npub[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        spins = 0;
+        VS_DIAG_ADD(dg, 0)
+      } else {
+        __builtin_amdgcn_s_sleep(2);
+        VS_DIAG_ADD(dg, 6)
+        if (++spins > VS_SPIN_LIMIT) {
+          if (args.err && lane == 0) atomicOr(args.err, 2);
+          break;
+        }
+      }
+    }
+#ifdef VS_DIAG
+    if (args.diag && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) args.diag[(size_t)blockIdx.x * 16 + 8 + k] = dg.acc[k];
+    }
+#endif
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * launch table
  * ---------------------------------------------------------------------------------------- */
@@ -628,11 +802,18 @@ static vs_kernel_fn vs_pick_log(bool log)
              : (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, false>;
 }
 
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, const VsKernelArgs *args,
-                                       unsigned grid, size_t lds_bytes, hipStream_t stream)
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
+                                       const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
+                                       hipStream_t stream)
 {
   vs_kernel_fn fn = nullptr;
-  if (arith == VS_ARITH_EXACT) {
+  unsigned block = VS_WAVE;
+  if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
+    fn = (arith == VS_ARITH_EXACT) ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT>
+                                   : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA>;
+    block = 2 * VS_WAVE;
+    lds_bytes += 2 * VS_WAVE * sizeof(int); /* gpub, npub */
+  } else if (arith == VS_ARITH_EXACT) {
     if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH>(log);
     else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
     else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER>(false);
@@ -648,6 +829,6 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, const VsKe
                                        (int)lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(VS_WAVE), lds_bytes, stream, *args);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds_bytes, stream, *args);
   return hipGetLastError();
 }
