@@ -101,7 +101,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:  # launched by torch.distributed.run: one rank per GPU over RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -125,7 +126,7 @@ def main():
         plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -146,7 +147,7 @@ def main():
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     k = torch.tensor([sum(kern_ms) / len(kern_ms)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -257,7 +258,7 @@ def main():
 
     plan.close()
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

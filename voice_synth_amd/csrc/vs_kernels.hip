@@ -100,18 +100,14 @@ struct VsGen {
   int T4, T, g, wpos, cyc;
 };
 
-/* next draw of the lane's sequential stream = what random() returns in the shimmed reference */
-__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, bool active)
+/* next draw of the lane's sequential stream = what random() returns in the shimmed reference.
+ * Called under the EXEC mask of the lanes that draw. */
+__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s)
 {
   const uint32_t b = s.d >> 2;
-  const bool need = active && (b != s.blk_idx);
-  if (__any(need)) {
-    uint32_t o0, o1, o2, o3;
-    vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-    if (need) {
-      s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
-      s.blk_idx = b;
-    }
+  if (b != s.blk_idx) {
+    vs_philox(b, c.key0, c.key1, s.b0, s.b1, s.b2, s.b3);
+    s.blk_idx = b;
   }
   /* word (d & 3) of the cached block; written as 64-bit select + shift so that the compiler
    * does not turn a four-way select into an indexed scratch array */
@@ -119,7 +115,7 @@ __device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, bool activ
   const uint64_t q1 = (uint64_t)s.b2 | ((uint64_t)s.b3 << 32);
   const uint64_t q = (s.d & 2u) ? q1 : q0;
   const uint32_t v = (uint32_t)(q >> ((s.d & 1u) * 32u));
-  if (active) s.d += 1u;
+  s.d += 1u;
   return v >> 1;
 }
 
@@ -167,70 +163,55 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
 }
 
 /* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
- * at most once, at i == thr (= C - wpos).  Lanes that must not emit write to a per-lane trash
- * slot (row C of the ring) instead, so the generator loops stay free of exec-mask branches. */
-__device__ __forceinline__ int vs_ring_index(int wpos, int thr, int C, int i, int lane, bool ok)
+ * at most once, at i == thr (= C - wpos). */
+__device__ __forceinline__ int vs_ring_at(int wpos, int thr, int C, int i, int lane)
 {
-  const int slot = wpos + i - ((i >= thr) ? C : 0);
-  return (ok ? slot : C) * VS_WAVE + lane;
+  return (wpos + i - ((i >= thr) ? C : 0)) * VS_WAVE + lane;
 }
 
 /*
- * One generator round: every lane with want == true produces one glottal cycle.
- * Statement-by-statement restatement of flowgen_shimmer.c:248-423 (see oracle/vs_oracle.c for
- * the scalar form); loops run in lock-step over the wavefront with per-lane predicates.
+ * One glottal cycle of every lane that is ACTIVE in the EXEC mask (the caller wraps the call in
+ * "if (want)"): statement-by-statement restatement of flowgen_shimmer.c:248-423 (scalar form:
+ * oracle/vs_oracle.c).  Plain SIMT code: loops have per-lane trip counts and the hardware
+ * masks lanes that are done; because all lanes walk the same phase of their own cycle together
+ * the masks are nearly full.  Within a loop trip the samples are computed stage by stage so
+ * that independent dependency chains interleave (one wavefront per SIMD issues a dependent
+ * instruction every ~8 ticks, an independent one every ~5: tools/ubench).
  * ltab is this wavefront's copy of the cos rows in LDS, c.tab_off the lane's row in it.
  */
 template <bool LOG>
 __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int16_t *ring, int C,
-                                                  int lane, int N, bool want, const double *ltab,
+                                                  int lane, int N, const double *ltab,
                                                   vs_cycle_rec *logrow, int log_cap, VsDiag &dg)
 {
   VS_DIAG_ADD(dg, 7)
   /* ---- jitter: fg:248-291 ---- */
-  {
-    const bool on = want && (c.flags & VS_DF_JITTER);
+  if (c.flags & VS_DF_JITTER) {
     const float dp1 = s.dp0; /* DeltaPer[1] = DeltaPer[0] */
-    bool pend = on;
-    while (__any(pend)) {
-      const uint32_t r = vs_draw(c, s, pend);
+    for (;;) {
+      const uint32_t r = vs_draw(c, s);
       const float J = (float)(((double)r / (2147483647 * 10000.0)) * 40000.0 * (double)c.jitter -
                               2.0 * (double)c.jitter);
       const double Jd = (double)J;
-      const float dp0 = (float)((double)dp1 * (2.0 + Jd) / (2.0 - Jd) +
-                                2.0 * (double)c.P * Jd / (2.0 - Jd));
-      const int Tn = vs_short_of(ceil((double)((float)c.P + dp0)));
-      const bool reject = ((float)Tn > c.t_hi) || ((float)Tn < c.t_lo);
-      if (pend) {
-        s.dp0 = dp0;
-        s.T = Tn;
-        pend = reject;
-      }
+      s.dp0 = (float)((double)dp1 * (2.0 + Jd) / (2.0 - Jd) + 2.0 * (double)c.P * Jd / (2.0 - Jd));
+      s.T = vs_short_of(ceil((double)((float)c.P + s.dp0)));
+      if (!(((float)s.T > c.t_hi) || ((float)s.T < c.t_lo))) break;
     }
   }
 
   /* ---- shimmer: fg:293-313 ---- */
   float Amplitude = (float)c.amp;
   float S = 0.0f;
-  {
-    const bool on = want && (c.flags & VS_DF_SHIMMER);
+  if (c.flags & VS_DF_SHIMMER) {
     const float ds1 = s.ds0;
-    bool pend = on;
-    while (__any(pend)) {
-      const uint32_t r = vs_draw(c, s, pend);
+    for (;;) {
+      const uint32_t r = vs_draw(c, s);
       const float epsilon = (float)r / 2147483648.0f; /* (float)RAND_MAX == 2^31 */
-      const float Sn = (float)((double)epsilon * 4.0 * (double)c.shimmer - 2.0 * (double)c.shimmer);
-      const double Sd = (double)Sn;
-      const float ds0 = (float)((double)ds1 * (2.0 + Sd) / (2.0 - Sd) +
-                                2.0 * (double)c.amp * Sd / (2.0 - Sd));
-      const float An = (float)c.amp + ds0;
-      const bool reject = (An > c.a_hi) || (An < c.a_lo);
-      if (pend) {
-        s.ds0 = ds0;
-        S = Sn;
-        Amplitude = An;
-        pend = reject;
-      }
+      S = (float)((double)epsilon * 4.0 * (double)c.shimmer - 2.0 * (double)c.shimmer);
+      const double Sd = (double)S;
+      s.ds0 = (float)((double)ds1 * (2.0 + Sd) / (2.0 - Sd) + 2.0 * (double)c.amp * Sd / (2.0 - Sd));
+      Amplitude = (float)c.amp + s.ds0;
+      if (!((Amplitude > c.a_hi) || (Amplitude < c.a_lo))) break;
     }
   }
 
@@ -238,41 +219,63 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   const int T = s.T;
   const int T2 = c.T2;
   const int room = N - s.g; /* samples of this cycle that still belong to the utterance */
-  const double Ad = (double)Amplitude;
-  const double *trow = ltab + c.tab_off;
-  float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
-
-  /* ---- rising half-pulse: fg:318-324.  Four samples per trip so the LDS reads overlap;
-   * everything is a select, not a branch (lanes differ in T2, T4 and their emit limit) ---- */
-  const double Ah = Ad * 0.5; /* "Amplitude * 0.5 * (...)" evaluates (Amplitude*0.5) first */
-  const float dcsf = (float)c.dcs;
   const int lim = (T < room) ? T : room; /* samples of this cycle that are emitted */
   const int wthr = C - s.wpos;
-  for (int i0 = 0; __any(want && i0 < T2); i0 += 4) {
-    double cs[4];
+  const double Ad = (double)Amplitude;
+  const double Ah = Ad * 0.5; /* "Amplitude * 0.5 * (...)" evaluates (Amplitude*0.5) first */
+  const float dcsf = (float)c.dcs;
+  const double *trow = ltab + c.tab_off;
+  float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
+  int T4 = s.T4;
+
+  /* ---- rising half-pulse: fg:318-324 ---- */
+  {
+    const int nE = (T2 < lim) ? T2 : lim; /* rising samples that are emitted */
+    int i = 0;
+    for (; i + 4 <= nE; i += 4) {
+      double v[4];
+      int xs0[4];
+      float xf0[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cs[k] = trow[(i0 + k < T2) ? (i0 + k) : 0];
+      for (int k = 0; k < 4; ++k) v[k] = trow[i + k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = i0 + k;
-      const bool act = want && (i < T2);
-      const int xs0 = vs_short_of(ceil(Ah * (1.0 - cs[k])));
+      for (int k = 0; k < 4; ++k) v[k] = 1.0 - v[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = Ah * v[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ceil(v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xs0[k] = vs_short_of(v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xf0[k] = (float)xs0[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool lt = xf0[k] < c.DC; /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
+        const int xs = lt ? c.dcs : xs0[k];
+        const float xf = lt ? dcsf : xf0[k];
+        T4 = lt ? (i + k) : T4;
+        psum = (lt ? 0.0f : psum) + xf * xf;
+        ring[vs_ring_at(s.wpos, wthr, C, i + k, lane)] = (int16_t)xs;
+      }
+    }
+    for (; i < T2; ++i) { /* remainder, and (last cycle of the utterance) samples past the end */
+      const int xs0 = vs_short_of(ceil(Ah * (1.0 - trow[i])));
       const float xf0 = (float)xs0;
-      const bool lt = act && (xf0 < c.DC); /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
+      const bool lt = xf0 < c.DC;
       const int xs = lt ? c.dcs : xs0;
       const float xf = lt ? dcsf : xf0;
-      s.T4 = lt ? i : s.T4;
-      const float pn = (lt ? 0.0f : psum) + xf * xf;
-      psum = act ? pn : psum;
-      ring[vs_ring_index(s.wpos, wthr, C, i, lane, act && (i < lim))] = (int16_t)xs;
+      T4 = lt ? i : T4;
+      psum = (lt ? 0.0f : psum) + xf * xf;
+      if (i < lim) ring[vs_ring_at(s.wpos, wthr, C, i, lane)] = (int16_t)xs;
     }
   }
+  s.T4 = T4;
 
   VS_DIAG_ADD(dg, 1)
   /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
   float Knew;
   {
-    const uint32_t r = vs_draw(c, s, want);
+    const uint32_t r = vs_draw(c, s);
     Knew = (float)((double)c.K * (1.0 + (double)(2.0f * c.Kvar) * (vs_unit_of_draw(r) - 0.5)));
   }
   const double Kd = (double)Knew;
@@ -280,57 +283,65 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   /* ---- falling half-pulse: fg:327-332 ---- */
   int T3 = 2 * T2;
   {
-    bool run = want;
-    for (int k0 = 0; __any(run && k0 < T2); k0 += 4) {
-      double cs[4];
+    bool run = true;
+    for (int k0 = 0; run && (k0 < T2); k0 += 4) {
+      double v[4];
+      int xsv[4];
+      float xfv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) cs[k] = trow[(k0 + k < T2) ? (k0 + k) : 0];
+      for (int k = 0; k < 4; ++k) v[k] = trow[(k0 + k < T2) ? (k0 + k) : 0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = Kd * v[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] - Kd;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = v[k] + 1.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = Ad * v[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ceil(v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xsv[k] = vs_short_of(v[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xfv[k] = (float)xsv[k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = T2 + k0 + k;
         const bool act = run && (k0 + k < T2);
-        const int xs = vs_short_of(ceil(Ad * (Kd * cs[k] - Kd + 1.0)));
-        const float xf = (float)xs;
-        const bool brk = act && (xf < c.DC); /* if(x[i] < par.DC) break; */
+        const bool brk = act && (xfv[k] < c.DC); /* if(x[i] < par.DC) break; */
         T3 = brk ? i : T3;
         run = run && !brk;
         const bool keep = act && !brk;
-        psum = keep ? (psum + xf * xf) : psum;
-        ring[vs_ring_index(s.wpos, wthr, C, i, lane, keep && (i < lim))] = (int16_t)xs;
+        psum = keep ? (psum + xfv[k] * xfv[k]) : psum;
+        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, wthr, C, i, lane) : (C * VS_WAVE + lane)] =
+            (int16_t)xsv[k];
       }
     }
   }
 
   VS_DIAG_ADD(dg, 2)
   float x_pow = 0.0f, w_pow = 0.0f;
-  const bool noisy = want && (c.flags & VS_DF_NOISE);
+  const bool noisy = (c.flags & VS_DF_NOISE) != 0;
 
-  /* ---- closed phase without noise: fg:334-336 ---- */
-  for (int i0 = 0; __any(want && !noisy && (T3 + i0 < lim)); i0 += 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = T3 + i0 + k;
-      ring[vs_ring_index(s.wpos, wthr, C, i, lane, want && !noisy && (i < lim))] = (int16_t)c.dcs;
-    }
-  }
-
-  VS_DIAG_ADD(dg, 3)
-  /* ---- closed phase with noise: fg:373-411 ---- */
-  if (__any(noisy)) {
-    x_pow = psum / ((float)T3 - (float)s.T4);
-    const float aux = (float)(1.0 + (double)(((float)T3 - (float)s.T4) / ((float)T)));
+  if (!noisy) {
+    /* ---- closed phase without noise: fg:334-336 ---- */
+    for (int i = T3; i < lim; ++i) ring[vs_ring_at(s.wpos, wthr, C, i, lane)] = (int16_t)c.dcs;
+    VS_DIAG_ADD(dg, 3)
+  } else {
+    /* ---- closed phase with noise: fg:373-411 ---- */
+    x_pow = psum / ((float)T3 - (float)T4);
+    const float aux = (float)(1.0 + (double)(((float)T3 - (float)T4) / ((float)T)));
     const float arg = 12.0f * aux * x_pow / c.noise;
-    const int NDW = noisy ? vs_isqrt_floor((double)arg) : 0;
+    const int NDW = vs_isqrt_floor((double)arg);
     const double NDWd = (double)NDW;
     const double half = NDWd / 2.0;
-    const int T4 = s.T4;
     const int ntail = (T > T3) ? (T - T3) : 0;
-    const int m = noisy ? (T4 + ntail) : 0; /* draws this cycle: [0,T4) then [T3,T) */
+    const int m = T4 + ntail; /* draws this cycle: [0,T4) then [T3,T) */
     const uint32_t d0 = s.d;
     const uint32_t bfirst = d0 >> 2;
     const int nblk = (m > 0) ? (int)(((d0 + (uint32_t)m - 1u) >> 2) - bfirst) + 1 : 0;
     float wsum = 0.0f;
-    if (!__any(noisy && (T4 > 0))) {
+    if (T4 == 0) {
       /* usual case (DC flow 0.25 after -n: T4 == 0): the draws map to i = T3 + q, q = 0..m-1 */
       int mlim = lim - T3;
       mlim = (mlim < m) ? mlim : m;
@@ -339,48 +350,59 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
       if (slot0 >= C) slot0 -= C;
       const int qthr = C - slot0;       /* first q whose slot wraps */
       int q0 = (int)(4u * bfirst - d0); /* ordinal of word 0 of the first block, -3..0 */
-      for (int bi = 0; __any(bi < nblk); ++bi) {
-        const bool bact = bi < nblk;
+      /* two Philox blocks (8 draws) per trip: their dependency chains interleave */
+      for (int bi = 0; bi < nblk; bi += 2) {
         const uint32_t b = bfirst + (uint32_t)bi;
-        uint32_t o0, o1, o2, o3;
-        vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-        if (bact) {
-          s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
-          s.blk_idx = b;
-        }
+        uint32_t o[8];
+        vs_philox(b, c.key0, c.key1, o[0], o[1], o[2], o[3]);
+        vs_philox(b + 1u, c.key0, c.key1, o[4], o[5], o[6], o[7]);
+        /* keep the last block this lane really used: the next cycle's first draws come from it */
+        const bool two = bi + 1 < nblk;
+        s.b0 = two ? o[4] : o[0];
+        s.b1 = two ? o[5] : o[1];
+        s.b2 = two ? o[6] : o[2];
+        s.b3 = two ? o[7] : o[3];
+        s.blk_idx = two ? (b + 1u) : b;
+        double u8[8];
+        int wv8[8];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
+        for (int w = 0; w < 8; ++w) u8[w] = vs_unit_of_draw(o[w] >> 1);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) u8[w] = u8[w] * NDWd;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) u8[w] = u8[w] - half;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) u8[w] = ceil(u8[w]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) wv8[w] = vs_short_of(u8[w]);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
           const int q = q0 + w;
-          const double u = vs_unit_of_draw(ow >> 1);
-          const int wv = vs_short_of(ceil(u * NDWd - half));
           if (LOG) {
-            if (bact && ((unsigned)q < (unsigned)m)) wsum += (float)wv * (float)wv;
+            if ((unsigned)q < (unsigned)m) wsum += (float)wv8[w] * (float)wv8[w];
           }
-          int xv = c.dcs + wv;
+          /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0); x[i] = truncate(DC + w) */
+          int xv = c.dcs + wv8[w];
           xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-          const bool ok = bact && ((unsigned)q < (unsigned)mlim);
+          const bool ok = (unsigned)q < (unsigned)mlim;
           const int slot = slot0 + q - ((q >= qthr) ? C : 0);
           ring[(ok ? slot : C) * VS_WAVE + lane] = (int16_t)xv;
         }
-        q0 += 4;
+        q0 += 8;
       }
     } else {
       /* general case: draws cover [0,T4) then [T3,T) */
-      for (int bi = 0; __any(bi < nblk); ++bi) {
-        const bool bact = bi < nblk;
+      for (int bi = 0; bi < nblk; ++bi) {
         const uint32_t b = bfirst + (uint32_t)bi;
         uint32_t o0, o1, o2, o3;
         vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-        if (bact) {
-          s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
-          s.blk_idx = b;
-        }
+        s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
+        s.blk_idx = b;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
           const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
-          const bool act = bact && (q >= 0) && (q < m);
+          const bool act = (q >= 0) && (q < m);
           const int i = (q < T4) ? q : (T3 + (q - T4));
           /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
           const double u = vs_unit_of_draw(ow >> 1);
@@ -390,23 +412,23 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
            * a monotone rising flank, on [0,T4) too -- but an amplitude above 32767 wraps the
            * (short) conversion and leaves genuine pulse samples below T4, so those are read
            * back from the ring */
-          int slot = s.wpos + i;
-          if (slot >= C) slot -= C;
-          int base = c.dcs;
-          if (act && (q < T4) && (i < lim)) base = (int)ring[slot * VS_WAVE + lane];
-          int xv = base + wv;
-          xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-          if (act && (i < lim)) ring[slot * VS_WAVE + lane] = (int16_t)xv;
+          if (act && (i < lim)) {
+            const int idx = vs_ring_at(s.wpos, wthr, C, i, lane);
+            const int base = (q < T4) ? (int)ring[idx] : c.dcs;
+            int xv = base + wv;
+            xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
+            ring[idx] = (int16_t)xv;
+          }
         }
       }
     }
-    if (noisy) s.d = d0 + (uint32_t)m;
+    s.d = d0 + (uint32_t)m;
     w_pow = wsum / (float)T;
+    VS_DIAG_ADD(dg, 4)
   }
 
-  VS_DIAG_ADD(dg, 4)
   if (LOG) {
-    if (want && logrow && s.cyc < log_cap) {
+    if (logrow && s.cyc < log_cap) {
       vs_cycle_rec rec;
       rec.S = S;
       rec.x_pow = noisy ? x_pow : 0.0f;
@@ -417,13 +439,11 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   }
 
   /* ---- emit bookkeeping: fg:413-423 ---- */
-  if (want) {
-    s.cyc += 1;
-    s.g += T;
-    int wp = s.wpos + T;
-    if (wp >= C) wp -= C;
-    s.wpos = wp;
-  }
+  s.cyc += 1;
+  s.g += T;
+  int wp = s.wpos + T;
+  if (wp >= C) wp -= C;
+  s.wpos = wp;
   VS_DIAG_ADD(dg, 5)
 }
 
@@ -613,7 +633,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
       const int n_ready = __builtin_popcountll(__ballot(ready));
       const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * args.ready_min) || !__any(want));
       if (!filter_now) {
-        vs_generate_cycle<LOG>(c, s, ring, C, lane, N, want, ltab, logrow, (int)args.log_pitch, dg);
+        if (want) vs_generate_cycle<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
         continue;
       }
     }
@@ -711,7 +731,7 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
       const int n_need = __builtin_popcountll(__ballot(need));
       const int n_want = __builtin_popcountll(__ballot(want));
       if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
-        vs_generate_cycle<false>(c, s, ring, C, lane, N, want, ltab, nullptr, 0, dg);
+        if (want) vs_generate_cycle<false>(c, s, ring, C, lane, N, ltab, nullptr, 0, dg);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(&gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         spins = 0;
