@@ -76,8 +76,11 @@ typedef struct vs_lane {
   float gain;         /* vowel -g                                           vw:131 */
   float pre_emphasis; /* vowel -p                                           vw:126 */
   int32_t vowel;      /* 'a','i','u','1'..'7', or VS_VOWEL_CUSTOM           vw:152 */
-  int32_t reserved;
+  float out_snr;      /* vowel -n: linear SNR pow(10, x/10) of the white noise added to the
+                         filtered signal frame by frame, 0 = off                vw:141-143, 302-324 */
   double A[VS_NCOEF]; /* A(z) when vowel == VS_VOWEL_CUSTOM; A[0] must be 1.0 */
+  uint64_t out_seed;  /* Philox key of the vowel stage's own draw stream (the reference's vowel
+                         process calls srandom(time) itself, vw:234): one draw per sample */
 } vs_lane;
 
 /* Per-cycle diagnostics the reference prints inside its loop (flowgen_shimmer.c:307, 409).

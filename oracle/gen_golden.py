@@ -69,6 +69,10 @@ def main():
     add("edge_dur_frac", ["-r", "11025", "-d", "0.77", "-j", "2", "-n", "15"], ["-v", "5"], 17)
     add("edge_dc_max", g16 + ["-l", "0.25", "-n", "25", "-j", "0.5"], ["-v", "7", "-g", "3"], 18)
     add("edge_cq1", g16 + ["-c", "1", "-j", "5", "-n", "20"], ["-v", "a", "-g", "1"], 19)
+    # --- vowel -n: white noise added to the filtered signal frame by frame (vowel_new.c:302-324) ---
+    add("onoise_cfg3", g16 + ["-j", "1", "-s", "5.76", "-n", "20"], ["-v", "1", "-n", "20"], 20)
+    add("onoise_22k", ["-d", "2", "-j", "1", "-n", "10"], ["-v", "4", "-g", "2", "-n", "5"], 21)
+    add("onoise_frac", ["-r", "11025", "-d", "0.77"], ["-v", "a", "-n", "35", "-p", "0.3"], 22)
     add("edge_seed64", g16 + ["-j", "1", "-s", "5.76", "-n", "20"], ["-v", "4"], 0xFEDCBA9876543210)
 
     manifest = []

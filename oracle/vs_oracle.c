@@ -232,21 +232,53 @@ int vs_oracle_filter(const vs_lane *lane, size_t n_samples, const int16_t *flow,
 
   for (int j = 0; j < VS_ORDER + 1; j++) y_double[j] = 0.0;
 
-  for (size_t i = 0; i < n_samples; i++) {
-    /* zeros: B = {1, 0, ...}; the j >= 1 terms add (+-0)*gain and cannot change y_double[0]
-     * (vowel_new.c:266-269, 435-448) */
-    y_double[0] = 0.0;
-    y_double[0] = y_double[0] + B0 * flow[i] * gain;
-    /* poles, vowel_new.c:279-281 */
-    for (int j = 1; j < VS_ORDER + 1; j++) {
-      y_double[0] = y_double[0] - A[j] * y_double[j];
+  /* frame length, vowel_new.c:361-363 (header.nSamplesPerSec is an unsigned long) */
+  const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
+  const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
+  const size_t Lframe = (size_t)(50 * milisec1);
+  const float snr = lane->out_snr;
+  vs_draw_stream rng;
+  vs_draw_init(&rng, lane->out_seed);
+  if (snr > 0 && Lframe == 0) return VS_ERR_RANGE;
+
+  size_t f0 = 0;
+  while (f0 < n_samples) {
+    const size_t ni = (snr > 0) ? ((n_samples - f0 < Lframe) ? n_samples - f0 : Lframe)
+                                : n_samples - f0; /* frames only matter to the noise */
+    int16_t *y = pcm + f0;
+    for (size_t k = 0; k < ni; k++) {
+      const size_t i = f0 + k;
+      /* zeros: B = {1, 0, ...}; the j >= 1 terms add (+-0)*gain and cannot change y_double[0]
+       * (vowel_new.c:266-269, 435-448) */
+      y_double[0] = 0.0;
+      y_double[0] = y_double[0] + B0 * flow[i] * gain;
+      /* poles, vowel_new.c:279-281 */
+      for (int j = 1; j < VS_ORDER + 1; j++) {
+        y_double[0] = y_double[0] - A[j] * y_double[j];
+      }
+      /* pre-emphasis on the output only, vowel_new.c:284 */
+      y[k] = vs_oracle_round2int(y_double[0] - pre_emphasis * y_double[1]);
+      /* shift, vowel_new.c:287-289 */
+      for (int j = VS_ORDER; j > 0; j--) {
+        y_double[j] = y_double[j - 1];
+      }
     }
-    /* pre-emphasis on the output only, vowel_new.c:284 */
-    pcm[i] = vs_oracle_round2int(y_double[0] - pre_emphasis * y_double[1]);
-    /* shift, vowel_new.c:287-289 */
-    for (int j = VS_ORDER; j > 0; j--) {
-      y_double[j] = y_double[j - 1];
+    /* noise added to the filtered frame, vowel_new.c:302-324 */
+    if (snr > 0) {
+      float aux, sig_power, NoiseDistWidth, noiseval;
+      aux = 0.0;
+      for (size_t k = 0; k < ni; k++) {
+        aux += (float)y[k] * y[k];
+      }
+      sig_power = aux / (float)ni;
+      NoiseDistWidth = sqrt(12 * sig_power / snr);
+      for (size_t k = 0; k < ni; k++) {
+        noiseval = (1.0 * vs_draw_next(&rng)) / VS_RAND_MAX;
+        aux = NoiseDistWidth * (noiseval - 0.5);
+        y[k] = vs_oracle_round2int(1.0 * y[k] + 1.0 * aux);
+      }
     }
+    f0 += ni;
   }
   return VS_OK;
 }

@@ -34,7 +34,7 @@ def _run(name, tmp_path, header):
     return c, fg, vw, open(tmp_path / "g.wav", "rb").read(), open(tmp_path / "o.wav", "rb").read()
 
 
-@pytest.mark.parametrize("name", ["ka_g16_va", "cfg3_lane0", "edge_dc_kvar", "cfg4_lane2", "edge_dur_frac"])
+@pytest.mark.parametrize("name", ["ka_g16_va", "cfg3_lane0", "edge_dc_kvar", "cfg4_lane2", "edge_dur_frac", "onoise_22k", "onoise_frac"])
 @pytest.mark.parametrize("header", [44, 72])
 def test_pipeline_files_match_reference(tmp_path, name, header):
     c, fg, vw, g, o = _run(name, tmp_path, header)

@@ -82,7 +82,9 @@ def lane_from_cli(flowgen_args, vowel_args, seed=0):
     lane.gain = vc.gain
     lane.pre_emphasis = vc.pre_emphasis
     lane.vowel = vc.vowel
+    lane.out_snr = vc.snr if vc.noise_arg != -1 else 0.0
     lane.seed = seed
+    lane.out_seed = seed  # the two reference processes read the same VS_SEED in the shimmed build
     return lane, fc.dur
 
 
@@ -106,6 +108,7 @@ def lanes_from_specs(specs):
             raise ValueError("all lanes of a batch share one duration")
         C.memmove(C.byref(arr[i]), C.byref(proto), C.sizeof(Lane))
         arr[i].seed = seed
+        arr[i].out_seed = seed
     return arr, dur
 
 

@@ -57,8 +57,9 @@ class Lane(C.Structure):
         ("gain", C.c_float),
         ("pre_emphasis", C.c_float),
         ("vowel", C.c_int32),
-        ("reserved", C.c_int32),
+        ("out_snr", C.c_float),
         ("A", C.c_double * VS_NCOEF),
+        ("out_seed", C.c_uint64),
     ]
 
 
@@ -111,7 +112,10 @@ class DevLane(C.Structure):
         ("key0", C.c_uint32),
         ("key1", C.c_uint32),
         ("row", C.c_int32),
-        ("pad", C.c_int32 * 4),
+        ("out_snr", C.c_float),
+        ("Lframe", C.c_int32),
+        ("okey0", C.c_uint32),
+        ("okey1", C.c_uint32),
     ]
 
 

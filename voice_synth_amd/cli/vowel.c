@@ -7,8 +7,8 @@
  * vs_filter(); the frame chunking of :237 and overlap() :392-400 only structure the
  * reference's file I/O (the filter state persists across frames), so the whole
  * payload is filtered in one call.
- *
- * Not implemented yet: "-n" output noise (vowel_new.c:302-324).
+ * "-n" (white noise added to the filtered signal frame by frame, vowel_new.c:302-324) runs on
+ * the device too: lane.out_snr / lane.out_seed.
  */
 #include <math.h>
 
@@ -43,6 +43,10 @@ int main(int argc, char **argv)
   lane.gain = cmd.gain;
   lane.pre_emphasis = cmd.pre_emphasis;
   lane.vowel = cmd.vowel;
+  if (cmd.noise_arg != -1) {
+    lane.out_snr = cmd.snr;         /* already pow(10, x/10), vowel_new.c:143 */
+    lane.out_seed = vs_cli_seed();  /* replaces srandom(time(NULL)), vowel_new.c:234 */
+  }
   rc = vs_lane_validate(&lane);
   if (rc != VS_OK) {
     fprintf(stderr, "vowel: -v %c: %s\n", (char)cmd.vowel, vs_strerror(rc));
@@ -50,12 +54,6 @@ int main(int argc, char **argv)
   }
   /* coefficients() prints the table label while the options are parsed, vowel_new.c:550-622 */
   printf("vowel %s", vs_vowel_name(cmd.vowel));
-
-  if (cmd.noise_arg != -1) {
-    fprintf(stderr, "\nvowel: -n (noise added to the filtered signal, vowel_new.c:302-324) is not "
-                    "implemented in this build\n");
-    return 2;
-  }
 
   /* input file, vowel_new.c:195-210 */
   FILE *fdr = fopen(argv[cmd.input_arg], "rb");
@@ -115,6 +113,7 @@ int main(int argc, char **argv)
   printf("Wait...");
 
   if (n) {
+    lane.fs = fs; /* the frame length of -n follows the input file's rate, vowel_new.c:361 */
     vs_ctx *ctx = NULL;
     if (vs_cli_open_ctx(&ctx) != VS_OK) return 1;
     rc = vs_filter(ctx, &lane, 1, n, x, y);

@@ -26,6 +26,7 @@
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
 
+extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
 extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream);
@@ -53,6 +54,8 @@ struct vs_plan {
   unsigned grid;
   unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
   int *d_err;                 /* spin-limit word of the wave-specialised kernel */
+  float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
+  long opow_pitch;
   int wave_specialised;
 };
 
@@ -193,6 +196,16 @@ extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
   d->key0 = (uint32_t)lane->seed;
   d->key1 = (uint32_t)(lane->seed >> 32);
   d->row = row;
+  d->out_snr = lane->out_snr;
+  {
+    /* milisec1 = (int)(header.nSamplesPerSec * 0.001/2.0)*2; Lframe = 50*milisec1 (vowel_new.c:361-363) */
+    const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
+    const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
+    d->Lframe = 50 * milisec1;
+  }
+  if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED; /* fs < 2000: zero-length frames */
+  d->okey0 = (uint32_t)lane->out_seed;
+  d->okey1 = (uint32_t)(lane->out_seed >> 32);
   return VS_OK;
 }
 
@@ -255,9 +268,11 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     return VS_ERR_NOMEM;
   }
   int tmax = 1;
+  int min_lframe = 0; /* shortest frame among the lanes that ask for output noise */
   for (size_t l = 0; l < n_lanes; l++) {
     int rc = vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
     if (rc != VS_OK) return rc;
+    if (dl[l].out_snr > 0 && (min_lframe == 0 || dl[l].Lframe < min_lframe)) min_lframe = dl[l].Lframe;
     const int T2 = dl[l].T2;
     std::map<int, int>::iterator it = row_of_T2.find(T2);
     if (it == row_of_T2.end()) {
@@ -306,6 +321,8 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
   p->d_diag = nullptr;
   p->d_err = nullptr;
+  p->d_opow = nullptr;
+  p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   {
     /* VS_KERNEL=ws selects the experimental wave-specialised fused kernel (generator wave +
      * filter wave per 64 utterances).  It is bit-exact but SLOWER at the LDS capacity that keeps
@@ -318,6 +335,8 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, costab.size() * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+  if (e == hipSuccess && p->opow_pitch)
+    e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
   if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), ctx->stream);
   if (e == hipSuccess)
     e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
@@ -331,6 +350,7 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     if (p->d_lanes) (void)hipFree(p->d_lanes);
     if (p->d_costab) (void)hipFree(p->d_costab);
     if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_opow) (void)hipFree(p->d_opow);
     delete p;
     return VS_ERR_HIP;
   }
@@ -345,6 +365,7 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_lanes) (void)hipFree(p->d_lanes);
   if (p->d_costab) (void)hipFree(p->d_costab);
   if (p->d_err) (void)hipFree(p->d_err);
+  if (p->d_opow) (void)hipFree(p->d_opow);
   delete p;
 }
 
@@ -406,6 +427,8 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.ready_min = p->ready_min;
   a.diag = p->d_diag;
   a.err = p->d_err;
+  a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
+  a.opow_pitch = p->opow_pitch;
   a.gen_min = 32;
   {
     const char *gm = getenv("VS_GEN_MIN"); /* tuning knob for experiments */
@@ -416,8 +439,10 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);
   a.vec_ok = vec;
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr, p->wave_specialised != 0, &a,
-                               p->grid, p->lds_bytes, ctx->stream));
+  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr,
+                               p->wave_specialised != 0 && a.opow == nullptr, &a, p->grid,
+                               p->lds_bytes, ctx->stream));
+  if (a.opow) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream)); /* vowel -n, second half */
   return VS_OK;
 }
 

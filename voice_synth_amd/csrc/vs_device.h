@@ -33,7 +33,9 @@ typedef struct VsDevLane {
   uint32_t flags;     /* VS_DF_* */
   uint32_t key0, key1;/* Philox key */
   int32_t row;        /* output row of this lane */
-  int32_t pad[4];
+  float out_snr;      /* vowel -n: linear SNR of the noise added to the filtered signal, 0 = off */
+  int32_t Lframe;     /* 50 * ((int)(fs*0.001/2.0)*2), the frame the noise power is taken over (vowel_new.c:361-363) */
+  uint32_t okey0, okey1; /* Philox key of the vowel stage's draw stream */
 } VsDevLane;
 
 typedef struct VsKernelArgs {
@@ -51,6 +53,8 @@ typedef struct VsKernelArgs {
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
   int ready_min;      /* super-step threshold: ready lanes * 64 >= live lanes * ready_min */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
+  float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */
+  long opow_pitch;
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;

@@ -459,7 +459,8 @@ template <int ARITH, int KIND>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
-                                             int16_t *__restrict__ orow, int n, int N, bool vec_ok)
+                                             int16_t *__restrict__ orow, int n, int N, bool vec_ok,
+                                             int (&outv)[VS_SS])
 {
   int xin[VS_SS];
   if (KIND == VS_KIND_FILTER) {
@@ -482,7 +483,6 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
     for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
   }
 
-  int outv[VS_SS];
   if (KIND == VS_KIND_SOURCE) {
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
@@ -616,6 +616,9 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
   dg.t = vs_stamp();
 #endif
+  float fsum = 0.0f; /* vowel -n: running sum of y^2 of the current frame */
+  int fpos = 0, fidx = 0;
+  const int Lframe = L->Lframe;
   int n = 0;     /* this lane's position in its own utterance */
   int rslot = 0; /* ring slot of sample n */
   bool live = valid;
@@ -640,11 +643,32 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
     /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
     if (ready) {
+      int outv[VS_SS];
       vs_superstep<ARITH, KIND>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
-                                args.vec_ok != 0);
+                                args.vec_ok != 0, outv);
       if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
         if (rslot >= C) rslot = 0;
+      }
+      if (KIND != VS_KIND_SOURCE && args.opow) {
+        /* vowel -n, first half (vowel_new.c:303-307): aux += (float)y[i]*y[i] over each frame of
+         * Lframe samples, in sample order; the noise itself is added by vs_out_noise_kernel
+         * once the whole frame's power is known */
+        float *prow = args.opow + row * args.opow_pitch;
+#pragma unroll
+        for (int t = 0; t < VS_SS; ++t) {
+          if (n + t < N) {
+            const float f = (float)outv[t];
+            fsum += f * f;
+            fpos += 1;
+            if (fpos == Lframe || n + t == N - 1) {
+              prow[fidx] = fsum;
+              fidx += 1;
+              fsum = 0.0f;
+              fpos = 0;
+            }
+          }
+        }
       }
       n += VS_SS;
       if (n >= N) live = false;
@@ -765,8 +789,8 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
     int16_t *__restrict__ orow = args.out + row * args.out_pitch;
     int n = 0, rslot = 0, spins = 0;
     bool live = valid;
-    VsDiag dg;
 #ifdef VS_DIAG
+    VsDiag dg;
 #pragma unroll
     for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
     dg.t = vs_stamp();
@@ -780,8 +804,9 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
       const int n_ready = __builtin_popcountll(__ballot(ready));
       if ((n_ready > 0) && (n_ready * 64 >= n_live * args.ready_min)) {
         if (ready) {
+          int outv[VS_SS];
           vs_superstep<ARITH, VS_KIND_SYNTH>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
-                                             orow, n, N, args.vec_ok != 0);
+                                             orow, n, N, args.vec_ok != 0, outv);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
@@ -808,6 +833,59 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
     }
 #endif
   }
+}
+
+/*
+ * vowel -n, second half (reference vowel_new.c:307-320): white noise added to the filtered
+ * signal, frame by frame, once each frame's power is known.
+ *     sig_power = aux / (float)ni;  NoiseDistWidth = sqrt(12*sig_power/snr);        (float)
+ *     noiseval = (1.0*random())/RAND_MAX;  aux = NoiseDistWidth*(noiseval - 0.5);   (float)
+ *     y[i] = round2int(1.0*y[i] + 1.0*aux);
+ * The vowel process draws once per sample, in order, so draw n belongs to sample n: one Philox
+ * block serves four consecutive samples and every sample is independent -- a plain streaming
+ * kernel, 8 bytes in and out per thread, HBM-bound.  Lframe is a multiple of 100 (milisec1 is
+ * even), so four consecutive samples never straddle a frame.
+ */
+__global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args, long quads_per_lane)
+{
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long l = gid / quads_per_lane;
+  if (l >= (long)args.n_lanes) return;
+  const long qd = gid - l * quads_per_lane;
+  const VsDevLane *__restrict__ L = args.lanes + l;
+  const float snr = L->out_snr;
+  if (!(snr > 0.0f)) return;
+  const int N = args.n_samples;
+  const int i0 = (int)(qd * 4);
+  if (i0 >= N) return;
+  const long row = (long)L->row;
+  int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+  const int Lframe = L->Lframe;
+  const int fr = i0 / Lframe;
+  const int left = N - fr * Lframe;
+  const int ni = (left < Lframe) ? left : Lframe;
+  const float sig_power = args.opow[row * args.opow_pitch + fr] / (float)ni;
+  const float ndw = (float)sqrt((double)(12.0f * sig_power / snr));
+  uint32_t o[4];
+  vs_philox((uint32_t)qd, L->okey0, L->okey1, o[0], o[1], o[2], o[3]);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (i0 + w < N) {
+      const float noiseval = (float)vs_unit_of_draw(o[w] >> 1);
+      const float aux = (float)((double)ndw * ((double)noiseval - 0.5));
+      orow[i0 + w] = (int16_t)vs_round2int(1.0 * (double)orow[i0 + w] + 1.0 * (double)aux);
+    }
+  }
+}
+
+extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream)
+{
+  const long quads = ((long)args->n_samples + 3) / 4;
+  const long total = quads * (long)args->n_lanes;
+  const long blocks = (total + 255) / 256;
+  if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vs_out_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *args, quads);
+  return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------------------------
