@@ -38,7 +38,7 @@ $(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h include/voice_synth.h
 $(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
 
-clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel
+clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
 
 $(BINDIR)/%: $(PKG)/cli/%.c $(PKG)/cli/cli_common.h $(LIB) | $(BINDIR)
 	$(CC) -O2 -ffp-contract=off -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lvoicesynth -lm -Wl,-rpath,'$$ORIGIN/../lib'
@@ -51,7 +51,7 @@ resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(CSRC)/vs_kernels.hip
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel
+	rm -f $(CSRC)/*.o $(LIB) $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
 	$(MAKE) -C oracle clean
 
 .PHONY: all clis oracle resources clean diag

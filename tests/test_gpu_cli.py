@@ -56,3 +56,31 @@ def test_vowel_stdout_banner(tmp_path):
     c, fg, vw, g, o = _run("cfg4_lane2", tmp_path, 44)
     assert vw.stdout.startswith(b"vowel /i/ MNV \nMaurilio N. Vieira, 28 mar 97. \n")
     assert b"pre_emphasis= 1.00, gain=10.00, snr= 0.00\n" in vw.stdout
+
+
+def test_vs_batch_manifest(tmp_path):
+    """vs_batch: N utterances described by the reference's own command lines -> N .wav files,
+    one fused launch per distinct sample count; payloads equal the reference's outputs."""
+    names = ["cfg3_lane0", "cfg3_lane1", "cfg5_lane3", "cfg4_lane2", "onoise_22k", "edge_dc_kvar", "ka_g16_va"]
+    lines = ["# golden cases as a manifest", ""]
+    for i, n in enumerate(names):
+        c = CASES[n]
+        lines.append("seed=%d -o out%d.wav %s | %s" % (c["seed"], i, " ".join(c["flowgen_args"]), " ".join(c["vowel_args"])))
+    (tmp_path / "m.txt").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True,
+                       env=dict(os.environ, VS_WAV_HEADER="44"))
+    assert r.returncode == 0, r.stderr
+    assert b"7 utterances in 2 launch(es)" in r.stdout
+    for i, n in enumerate(names):
+        raw = open(tmp_path / ("out%d.wav" % i), "rb").read()
+        assert len(raw) == 44 + 2 * CASES[n]["n_samples"]
+        assert sha(raw[44:]) == CASES[n]["sha256_pcm"], n
+
+
+def test_vs_batch_rejects_what_the_reference_rejects(tmp_path):
+    (tmp_path / "m.txt").write_text("-o a.wav -r 22050 | -v a\n")     # explicit 22050 (SURVEY F7)
+    r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True)
+    assert r.returncode == 1 and b"usage()" in r.stderr
+    (tmp_path / "m.txt").write_text("-o a.wav -r 16000 | -v e\n")     # no 'e' table (SURVEY F11)
+    r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True)
+    assert r.returncode == 1

@@ -1,0 +1,180 @@
+/*
+ * vs_batch -- batch front-end over the C ABI: N utterances
+ * described by the REFERENCE's own command lines, synthesised in one fused GPU launch per
+ * distinct sample count, written as N .wav files.
+ *
+ *     vs_batch manifest.txt
+ *
+ * One utterance per manifest line:
+ *
+ *     [seed=N] <flowgen_shimmer arguments> | <vowel arguments>
+ *
+ * e.g.   seed=7 -o a1.wav -r 16000 -d 1 -j 1 -s 5.76 -n 20 | -v 1 -g 10
+ *
+ * The flowgen "-o" names the FINAL speech file (there is no intermediate flow file: the flow
+ * never leaves the chip); the vowel side takes -v, -g, -p, -n (its -i/-o are implied).
+ * Arguments are parsed by the same vs_flowgen_parse()/vs_vowel_parse() the drop-in programs
+ * use, so ranges, defaults and quirks are the reference's.  Without "seed=" a line's Philox key
+ * is VS_SEED (default: time) + line number.  Empty lines and lines starting with '#' are
+ * skipped.  Exit code 0 on success, 1 on any error (nothing is exit()ed from the library).
+ */
+#include <ctype.h>
+
+#include "cli_common.h"
+
+#define MAX_TOK 64
+
+typedef struct {
+  vs_lane lane;
+  float dur;
+  uint64_t n_samples;
+  char *path;
+  int done;
+} job;
+
+static int split(char *s, char **tok, int max)
+{
+  int n = 0;
+  while (*s && n < max - 1) {
+    while (*s && isspace((unsigned char)*s)) *s++ = 0;
+    if (!*s) break;
+    tok[n++] = s;
+    while (*s && !isspace((unsigned char)*s)) s++;
+  }
+  tok[n] = NULL;
+  return n;
+}
+
+int main(int argc, char **argv)
+{
+  if (argc != 2) {
+    fprintf(stderr, "usage: vs_batch manifest.txt\n"
+                    "  line: [seed=N] <flowgen_shimmer args incl. -o out.wav> | <vowel args: -v x [-g x] [-p x] [-n x]>\n");
+    return 1;
+  }
+  FILE *mf = fopen(argv[1], "r");
+  if (!mf) {
+    fprintf(stderr, "vs_batch: cannot open %s\n", argv[1]);
+    return 1;
+  }
+  size_t cap = 1024, n_jobs = 0;
+  job *jobs = (job *)malloc(cap * sizeof(job));
+  char line[4096];
+  const uint64_t seed0 = vs_cli_seed();
+  long lineno = 0;
+  while (jobs && fgets(line, sizeof(line), mf)) {
+    lineno++;
+    char *p = line;
+    while (*p && isspace((unsigned char)*p)) p++;
+    if (!*p || *p == '#') continue;
+    char *bar = strchr(p, '|');
+    if (!bar) {
+      fprintf(stderr, "vs_batch: line %ld: missing '|' between the flowgen and the vowel arguments\n", lineno);
+      return 1;
+    }
+    *bar = 0;
+    uint64_t seed = seed0 + (uint64_t)lineno;
+    char *ftok[MAX_TOK + 1], *vtok[MAX_TOK + 4];
+    ftok[0] = (char *)"flowgen_shimmer";
+    int nf = 1 + split(p, ftok + 1, MAX_TOK);
+    if (nf > 1 && strncmp(ftok[1], "seed=", 5) == 0) {
+      seed = (uint64_t)strtoull(ftok[1] + 5, NULL, 0);
+      memmove(ftok + 1, ftok + 2, (size_t)(nf - 1) * sizeof(char *));
+      nf--;
+    }
+    vtok[0] = (char *)"vowel";
+    vtok[1] = (char *)"-i";
+    vtok[2] = (char *)"-";
+    int nv = 3 + split(bar + 1, vtok + 3, MAX_TOK);
+    vs_flowgen_cmd fc;
+    vs_vowel_cmd vc;
+    int rc = vs_flowgen_parse(nf, ftok, &fc);
+    if (rc == VS_OK) rc = vs_vowel_parse(nv, vtok, &vc);
+    if (rc != VS_OK) {
+      fprintf(stderr, "vs_batch: line %ld: %s\n", lineno,
+              rc == VS_USAGE ? "arguments the reference would answer with usage()" : vs_strerror(rc));
+      return 1;
+    }
+    if (n_jobs == cap) {
+      cap *= 2;
+      jobs = (job *)realloc(jobs, cap * sizeof(job));
+      if (!jobs) break;
+    }
+    job *j = &jobs[n_jobs];
+    j->lane = fc.lane;
+    j->lane.gain = vc.gain;
+    j->lane.pre_emphasis = vc.pre_emphasis;
+    j->lane.vowel = vc.vowel;
+    j->lane.out_snr = (vc.noise_arg != -1) ? vc.snr : 0.0f;
+    j->lane.seed = seed;
+    j->lane.out_seed = seed;
+    j->dur = fc.dur;
+    vs_num_samples(fc.lane.fs, fc.dur, &j->n_samples);
+    j->path = strdup(ftok[fc.wav_arg]);
+    j->done = 0;
+    rc = vs_lane_validate(&j->lane);
+    if (rc != VS_OK) {
+      fprintf(stderr, "vs_batch: line %ld: %s\n", lineno, vs_strerror(rc));
+      return 1;
+    }
+    n_jobs++;
+  }
+  fclose(mf);
+  if (!jobs) {
+    fprintf(stderr, "vs_batch: out of memory\n");
+    return 1;
+  }
+  if (n_jobs == 0) {
+    fprintf(stderr, "vs_batch: empty manifest\n");
+    return 1;
+  }
+
+  vs_ctx *ctx = NULL;
+  if (vs_cli_open_ctx(&ctx) != VS_OK) return 1;
+  const int hb = vs_cli_header_bytes();
+  size_t remaining = n_jobs, launches = 0;
+  vs_lane *lanes = (vs_lane *)malloc(n_jobs * sizeof(vs_lane));
+  size_t *index = (size_t *)malloc(n_jobs * sizeof(size_t));
+  while (remaining && lanes && index) {
+    /* one launch per distinct sample count */
+    uint64_t ns = 0;
+    size_t m = 0;
+    for (size_t k = 0; k < n_jobs; k++) {
+      if (jobs[k].done) continue;
+      if (m == 0) ns = jobs[k].n_samples;
+      if (jobs[k].n_samples == ns) {
+        lanes[m] = jobs[k].lane;
+        index[m++] = k;
+      }
+    }
+    int16_t *pcm = (int16_t *)malloc(m * (size_t)ns * sizeof(int16_t));
+    if (!pcm) {
+      fprintf(stderr, "vs_batch: out of memory for %zu x %llu samples\n", m, (unsigned long long)ns);
+      return 1;
+    }
+    int rc = vs_synth(ctx, lanes, m, (size_t)ns, pcm);
+    if (rc != VS_OK) {
+      fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d)\n", vs_strerror(rc), vs_ctx_last_hip_error(ctx));
+      return 1;
+    }
+    for (size_t q = 0; q < m; q++) {
+      job *j = &jobs[index[q]];
+      unsigned char header[72];
+      int hbytes = vs_wav_header_write(header, hb, j->lane.fs, j->dur);
+      FILE *f = fopen(j->path, "wb");
+      if (!f || fwrite(header, (size_t)hbytes, 1, f) != 1 ||
+          fwrite(pcm + q * (size_t)ns, sizeof(int16_t), (size_t)ns, f) != (size_t)ns) {
+        fprintf(stderr, "vs_batch: cannot write %s\n", j->path);
+        return 1;
+      }
+      fclose(f);
+      j->done = 1;
+    }
+    free(pcm);
+    remaining -= m;
+    launches++;
+  }
+  printf("vs_batch: %zu utterances in %zu launch(es)\n", n_jobs, launches);
+  vs_ctx_destroy(ctx);
+  return 0;
+}
