@@ -91,3 +91,25 @@ def test_experimental_wave_specialised_kernel_bit_exact(monkeypatch):
             assert np.array_equal(got, po.synth(lanes, ns)), index
     finally:
         eng.close()
+
+
+def test_custom_coefficient_sets_per_lane(engine):
+    """VS_VOWEL_CUSTOM: every lane carries its own A(z) (here: the ten tables with their poles
+    pulled inwards by a per-lane radius, so all sets are distinct and stable)."""
+    import ctypes as C
+
+    base, ns = _lanes(3, 100)
+    ids = "aiu1234567"
+    for l in range(100):
+        a = vs.vowel_coefficients(ids[l % 10])
+        r = 0.90 + 0.001 * l
+        a = a * r ** np.arange(23)
+        base[l].vowel = 0
+        for j in range(23):
+            base[l].A[j] = float(a[j])
+        base[l].gain = 1.0 + 0.09 * l
+        base[l].pre_emphasis = (l % 11) / 10.0
+    engine.set_arith(vs.VS_ARITH_EXACT)
+    got = engine.synth(base, ns)
+    want = po.synth(base, ns)
+    assert np.array_equal(got, want)

@@ -166,7 +166,11 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
  * at most once, at i == thr (= C - wpos). */
 __device__ __forceinline__ int vs_ring_at(int wpos, int thr, int C, int i, int lane)
 {
-  return (wpos + i - ((i >= thr) ? C : 0)) * VS_WAVE + lane;
+  /* slot = (wpos + i) mod C for wpos + i < 2C, as min(s, s - C) on unsigned (two instructions) */
+  const unsigned sl = (unsigned)(wpos + i);
+  const unsigned wr = sl - (unsigned)C;
+  (void)thr;
+  return (int)((sl < wr) ? sl : wr) * VS_WAVE + lane;
 }
 
 /*
@@ -348,7 +352,6 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
       mlim = (mlim > 0) ? mlim : 0;
       int slot0 = s.wpos + T3; /* ring slot of q == 0; T3 <= P + 2 < C */
       if (slot0 >= C) slot0 -= C;
-      const int qthr = C - slot0;       /* first q whose slot wraps */
       int q0 = (int)(4u * bfirst - d0); /* ordinal of word 0 of the first block, -3..0 */
       /* two Philox blocks (8 draws) per trip: their dependency chains interleave */
       for (int bi = 0; bi < nblk; bi += 2) {
@@ -385,7 +388,8 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
           int xv = c.dcs + wv8[w];
           xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
           const bool ok = (unsigned)q < (unsigned)mlim;
-          const int slot = slot0 + q - ((q >= qthr) ? C : 0);
+          const unsigned sl = (unsigned)(slot0 + q), wr = sl - (unsigned)C; /* (slot0 + q) mod C */
+          const int slot = (int)((sl < wr) ? sl : wr);
           ring[(ok ? slot : C) * VS_WAVE + lane] = (int16_t)xv;
         }
         q0 += 8;
