@@ -1,0 +1,44 @@
+"""bench.py contract on the GPU box: one JSON line with the driver's keys + roofline +
+cpu_baseline; and the torch.distributed.run launch path (world size 1 here: RCCL init, barrier,
+all-reduce of the timings are exercised; more ranks are the driver's to launch)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _check(line, steps):
+    d = json.loads(line)
+    for k in KEYS:
+        assert k in d, k
+    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["scaling"] == "weak"
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["parity_check"]["mismatched_samples"] == 0
+    return d
+
+
+def test_bench_single_process_small():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lanes", "4096", "--steps", "3", "--warmup", "1",
+                          "--cpu-seconds", "0.5"], capture_output=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_under_torch_distributed_run():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--lanes", "4096", "--steps", "3",
+           "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    _check(lines[-1], 3)

@@ -98,3 +98,41 @@ def test_odd_sample_counts_and_pitches(engine):
         got = engine.synth(lanes, n)
         want = po.synth(lanes, n)
         assert np.array_equal(got, want), n
+
+
+def test_longest_supported_period_and_beyond(engine):
+    """fs/F0 near the LDS limit of the ring (one workgroup per CU), where the reference itself
+    overflows its w[500] buffer; and just beyond it -> VS_ERR_UNSUPPORTED, not a wrong answer."""
+    fa = ["-r", "44100", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5", "-s", "10", "-n", "15"]
+    lanes = []
+    for seed in range(70):
+        lane, dur = vs.lane_from_cli(fa, ["-v", "u", "-g", "3"], seed)
+        lanes.append(lane)
+    n = vs.num_samples(44100, dur)
+    got = engine.synth(lanes, n)
+    assert np.array_equal(got, po.synth(lanes, n))
+    lane, dur = vs.lane_from_cli(["-r", "48000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5"], ["-v", "a"], 1)
+    with pytest.raises(vs.VsError) as e:
+        engine.synth([lane], 1000)
+    assert e.value.code == vs._ffi.VS_ERR_UNSUPPORTED
+
+
+def test_mixed_batch_every_option_combination(engine):
+    """one batch whose lanes differ in everything: rate, F0, options on/off, vowel, output noise"""
+    specs = []
+    k = 0
+    for fs in ("8000", "16000", "44100"):
+        for opts in ([], ["-j", "2"], ["-s", "8"], ["-n", "12"], ["-j", "1", "-s", "3", "-n", "25", "-z", "0.4"],
+                     ["-n", "30", "-l", "0.2"], ["-c", "0.9", "-k", "1.0", "-j", "4"]):
+            for va in (["-v", "a"], ["-v", "5", "-g", "2", "-p", "0.4"], ["-v", "i", "-n", "15"]):
+                k += 1
+                specs.append((["-r", fs, "-d", "0.5", "-f", "%d" % (90 + 7 * (k % 20)), "-g", "%d" % (100 + 8 * (k % 20))] + opts,
+                              va, 1000 + k))
+    lanes = []
+    for fa, va, seed in specs:
+        lane, dur = vs.lane_from_cli(fa, va, seed)
+        lanes.append(lane)
+    n = 7777   # one sample count for the batch (durations differ in the reference; here n is the batch's)
+    got = engine.synth(lanes, n)
+    want = po.synth(lanes, n)
+    assert np.array_equal(got, want), int((got != want).sum())
