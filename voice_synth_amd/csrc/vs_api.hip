@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <new>
 #include <vector>
@@ -224,14 +225,15 @@ extern "C" void vs_cos_row(int T2, double *row)
  * up, which keeps both the rounds and the super-steps well attended; the policy table below
  * comes from replaying real period sequences through the scheduler.
  * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
-extern "C" int vs_ring_policy(int tmax, int *slots, int *ready_min)
+extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
 {
   const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
   const int need = ((VS_SS + tmax + VS_SS - 1) / VS_SS) * VS_SS;
   if (need > hard_limit) return VS_ERR_UNSUPPORTED;
-  int cap = 288; /* (288 + 1) rows * 128 B = 36.1 KiB + cos rows + sync words: four workgroups per CU */
+  if (cap <= 0) cap = 288; /* (288 + 1) rows * 128 B = 36.1 KiB + cos rows + sync words: four workgroups per CU */
   const char *env = getenv("VS_RING_SLOTS"); /* tuning knob for experiments */
-  if (env && *env) cap = (atoi(env) / VS_SS) * VS_SS;
+  if (env && *env) cap = atoi(env);
+  cap = (cap / VS_SS) * VS_SS;
   if (cap > hard_limit) cap = hard_limit;
   int want = ((VS_SS + (int)(1.7 * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
   if (want < 192) want = 192;
@@ -251,7 +253,7 @@ extern "C" int vs_ring_policy(int tmax, int *slots, int *ready_min)
   return VS_OK;
 }
 
-extern "C" int vs_ring_slots_for(int tmax, int *slots) { return vs_ring_policy(tmax, slots, nullptr); }
+extern "C" int vs_ring_slots_for(int tmax, int *slots) { return vs_ring_policy(tmax, 0, slots, nullptr); }
 
 extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                               vs_plan **out)
@@ -286,9 +288,51 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     }
     if (dl[l].tbound > tmax) tmax = dl[l].tbound;
   }
+  /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its
+   * longest lane and the cos rows of a wavefront are staged once per distinct T2, so a batch with
+   * an F0 sweep (BASELINE config 5) is sorted by (P, T2, options) before it is cut into groups of
+   * 64.  Placement is internal: each lane still writes its own output row (VsDevLane.row), and a
+   * lane's result does not depend on its neighbours.  Stable sort, so homogeneous batches keep
+   * their order. */
+  {
+    bool mixed = false;
+    for (size_t l = 1; l < n_lanes && !mixed; l++)
+      mixed = dl[l].P != dl[0].P || dl[l].T2 != dl[0].T2 || dl[l].flags != dl[0].flags;
+    if (mixed) {
+      std::stable_sort(dl.begin(), dl.end(), [](const VsDevLane &a, const VsDevLane &b) {
+        if (a.P != b.P) return a.P < b.P;
+        if (a.T2 != b.T2) return a.T2 < b.T2;
+        return a.flags < b.flags;
+      });
+    }
+  }
+  /* Launch shape.  A full chip is 4 x cu_count wavefronts, one per SIMD.
+   *  - at least that many 64-utterance groups: one wavefront per group, ring sized so that four
+   *    workgroups share a CU's 160 KiB of LDS;
+   *  - at most half of that (e.g. BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU):
+   *    the WAVE-SPECIALISED kernel -- a generator wavefront and a filter wavefront per group, each
+   *    with a SIMD of its own (two pairs per 256-thread workgroup when that makes one workgroup
+   *    per CU); 1.35-1.45x faster than leaving half of the SIMDs idle. */
+  const unsigned grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
+  const unsigned simds = 4u * (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+  int wave_specialised = (2u * grid <= simds);
+  {
+    const char *k = getenv("VS_KERNEL"); /* A/B knob: "ws" or "single" forces the choice */
+    if (k && strcmp(k, "ws") == 0) wave_specialised = 1;
+    if (k && strcmp(k, "single") == 0) wave_specialised = 0;
+  }
+  unsigned wg_per_cu = (grid + (unsigned)ctx->cu_count - 1) / (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  if (wg_per_cu > 4) wg_per_cu = 4;
+  int cap = 0; /* default: four workgroups per CU */
+  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (VS_WAVE * 2)) - 1;
   int slots = 0, ready_min = 32;
-  int rc = vs_ring_policy(tmax, &slots, &ready_min);
+  int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
   if (rc != VS_OK) return rc;
+  /* measured on 16384 / 32768 utterances (tools/gpu_sweep.sh): with a SIMD per wavefront the
+   * generator has slack, so it should feed the filter eagerly (rounds from 25 % attendance) and
+   * the filter should not wait for stragglers (super-steps from 62 %); ring size is immaterial */
+  if (wave_specialised && !getenv("VS_READY_MIN")) ready_min = 40;
   /* cos rows staged per wavefront: sum of the distinct T2 among its 64 lanes, worst wavefront */
   int ltab_entries = 0;
   for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
@@ -318,18 +362,12 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->ltab_entries = ltab_entries;
   /* ring rows + one trash row (lanes that must not emit write there) + the cos rows */
   p->lds_bytes = (size_t)(slots + 1) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
-  p->grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
+  p->grid = grid;
   p->d_diag = nullptr;
   p->d_err = nullptr;
   p->d_opow = nullptr;
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
-  {
-    /* VS_KERNEL=ws selects the experimental wave-specialised fused kernel (generator wave +
-     * filter wave per 64 utterances).  It is bit-exact but SLOWER at the LDS capacity that keeps
-     * four workgroups per CU, so the one-wave kernel is the default. */
-    const char *k = getenv("VS_KERNEL");
-    p->wave_specialised = (k && strcmp(k, "ws") == 0);
-  }
+  p->wave_specialised = wave_specialised;
 
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
@@ -429,7 +467,15 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.err = p->d_err;
   a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
   a.opow_pitch = p->opow_pitch;
-  a.gen_min = 32;
+  /* wave-specialised launch shape: two pairs per workgroup when that gives one workgroup per CU */
+  {
+    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+    a.ws_pairs = (p->grid > cus && p->grid <= 2u * cus) ? 2 : 1;
+    const char *wp = getenv("VS_WS_PAIRS"); /* tuning knob for experiments */
+    if (wp && *wp) a.ws_pairs = (atoi(wp) == 2) ? 2 : 1;
+    a.ws_pair_bytes = (int)((p->lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
+  }
+  a.gen_min = 16;
   {
     const char *gm = getenv("VS_GEN_MIN"); /* tuning knob for experiments */
     if (gm && *gm) a.gen_min = atoi(gm);

@@ -52,6 +52,8 @@ typedef struct VsKernelArgs {
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
   int ready_min;      /* super-step threshold: ready lanes * 64 >= live lanes * ready_min */
+  int ws_pairs;       /* wave-specialised kernel: generator/filter pairs per workgroup (1 or 2) */
+  int ws_pair_bytes;  /* LDS bytes of one pair: ring + trash row + cos rows + progress words, 16-byte multiple */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
   float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */
   long opow_pitch;

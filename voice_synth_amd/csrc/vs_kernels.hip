@@ -716,17 +716,23 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 #define VS_SPIN_LIMIT (1 << 22)
 
 template <int ARITH>
-__global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArgs args)
+__global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArgs args)
 {
-  extern __shared__ __attribute__((aligned(16))) int16_t ring[];
+  extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
 
-  const int wave = (int)threadIdx.x >> 6;
+  /* a workgroup holds ws_pairs generator/filter pairs (blockDim = 128 * ws_pairs): with two
+   * pairs (256 threads) and one workgroup per CU the four wavefronts land on the CU's four
+   * SIMDs, which two separate 128-thread workgroups are not guaranteed to do */
+  const int pair = (int)threadIdx.x >> 7;
+  const int wave = ((int)threadIdx.x >> 6) & 1;
   const int lane = (int)threadIdx.x & (VS_WAVE - 1);
-  const long gl = (long)blockIdx.x * VS_WAVE + lane;
+  const long group = (long)blockIdx.x * (long)(blockDim.x >> 7) + pair;
+  const long gl = group * VS_WAVE + lane;
   const bool valid = gl < (long)args.n_lanes;
   const VsDevLane *__restrict__ L = args.lanes + (valid ? gl : (long)args.n_lanes - 1);
   const int N = args.n_samples;
   const int C = args.ring_slots;
+  int16_t *ring = lds_base + (size_t)pair * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
   double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE);
   int *gpub = (int *)(ltab + args.ltab_entries);
   int *npub = gpub + VS_WAVE;
@@ -775,7 +781,7 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
 #ifdef VS_DIAG
     if (args.diag && lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) args.diag[(size_t)blockIdx.x * 16 + k] = dg.acc[k];
+      for (int k = 0; k < 8; ++k) args.diag[(size_t)group * 16 + k] = dg.acc[k];
     }
 #endif
     if (args.ncyc && valid) args.ncyc[row] = s.cyc;
@@ -833,7 +839,7 @@ __global__ void __launch_bounds__(2 * VS_WAVE, 2) vs_synth_ws_kernel(VsKernelArg
 #ifdef VS_DIAG
     if (args.diag && lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) args.diag[(size_t)blockIdx.x * 16 + 8 + k] = dg.acc[k];
+      for (int k = 0; k < 8; ++k) args.diag[(size_t)group * 16 + 8 + k] = dg.acc[k];
     }
 #endif
   }
@@ -913,8 +919,11 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_
   if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
     fn = (arith == VS_ARITH_EXACT) ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT>
                                    : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA>;
-    block = 2 * VS_WAVE;
-    lds_bytes += 2 * VS_WAVE * sizeof(int); /* gpub, npub */
+    /* lds_bytes arrives as the bytes of ONE pair (ring + cos rows + gpub/npub); args->ws_pairs
+     * pairs share a workgroup */
+    block = 2 * VS_WAVE * (unsigned)args->ws_pairs;
+    lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
+    grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
   } else if (arith == VS_ARITH_EXACT) {
     if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH>(log);
     else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
