@@ -30,7 +30,7 @@ def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
     n_samples = local.shape[1]
     if world == 1:
         return local
-    reqs = []
+    ops = []
     out = None
     if rank == dst:
         out = torch.empty((n_lanes_total, n_samples), dtype=local.dtype, device=local.device)
@@ -42,12 +42,14 @@ def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
             lo, hi = shard_range(n_lanes_total, r, world)
             step = chunk_rows or max(1, hi - lo)
             for a in range(lo, hi, step):
-                reqs.append(dist.irecv(out[a:min(hi, a + step)], src=r))
+                ops.append(dist.P2POp(dist.irecv, out[a:min(hi, a + step)], r))
     else:
         lo, hi = shard_range(n_lanes_total, rank, world)
         step = chunk_rows or max(1, hi - lo)
         for a in range(0, hi - lo, step):
-            reqs.append(dist.isend(local[a:min(hi - lo, a + step)].contiguous(), dst=dst))
-    for q in reqs:
+            ops.append(dist.P2POp(dist.isend, local[a:min(hi - lo, a + step)].contiguous(), dst))
+    # one coalesced group: with RCCL the seven receives of the root run concurrently, one per
+    # xGMI link, instead of one after the other
+    for q in dist.batch_isend_irecv(ops):
         q.wait()
     return out
