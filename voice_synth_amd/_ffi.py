@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoicesynth.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("VS_LIB", "libvoicesynth.so"))  # VS_LIB: A/B builds in tools/
 
 VS_ORDER = 22
 VS_NCOEF = 23

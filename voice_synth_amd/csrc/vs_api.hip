@@ -476,6 +476,11 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
     a.ws_pair_bytes = (int)((p->lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
   }
   a.gen_min = 16;
+  a.gen_low = 2 * VS_SS;
+  {
+    const char *gl = getenv("VS_GEN_LOW"); /* tuning knob for experiments */
+    if (gl && *gl) a.gen_low = atoi(gl);
+  }
   {
     const char *gm = getenv("VS_GEN_MIN"); /* tuning knob for experiments */
     if (gm && *gm) a.gen_min = atoi(gm);

@@ -57,6 +57,7 @@ typedef struct VsKernelArgs {
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
   float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */
   long opow_pitch;
+  int gen_low;        /* wave-specialised kernel: a lane with fewer buffered samples than this starts a round at once */
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;

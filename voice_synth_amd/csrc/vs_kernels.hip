@@ -98,6 +98,10 @@ struct VsGen {
   uint32_t d, blk_idx, b0, b1, b2, b3;
   float dp0, ds0;
   int T4, T, g, wpos, cyc;
+  /* the next cycle's period / amplitude once its jitter and shimmer draws are made
+   * (vs_cycle_scalars) and before its samples are written (vs_cycle_emit) */
+  float amp_next, S_next;
+  bool pend;
 };
 
 /* next draw of the lane's sequential stream = what random() returns in the shimmed reference.
@@ -174,19 +178,14 @@ __device__ __forceinline__ int vs_ring_at(int wpos, int thr, int C, int i, int l
 }
 
 /*
- * One glottal cycle of every lane that is ACTIVE in the EXEC mask (the caller wraps the call in
- * "if (want)"): statement-by-statement restatement of flowgen_shimmer.c:248-423 (scalar form:
- * oracle/vs_oracle.c).  Plain SIMT code: loops have per-lane trip counts and the hardware
- * masks lanes that are done; because all lanes walk the same phase of their own cycle together
- * the masks are nearly full.  Within a loop trip the samples are computed stage by stage so
- * that independent dependency chains interleave (one wavefront per SIMD issues a dependent
- * instruction every ~8 ticks, an independent one every ~5: tools/ubench).
- * ltab is this wavefront's copy of the cos rows in LDS, c.tab_off the lane's row in it.
+ * One glottal cycle of a lane is produced in two halves, vs_cycle_scalars() and vs_cycle_emit().
  */
-template <bool LOG>
-__device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int16_t *ring, int C,
-                                                  int lane, int N, const double *ltab,
-                                                  vs_cycle_rec *logrow, int log_cap, VsDiag &dg)
+/* First half of a cycle: the jitter and shimmer recursions with their rejection loops
+ * (flowgen_shimmer.c:248-313).  They only consume draws and fix the cycle's period T and
+ * amplitude -- no ring space is needed yet, so a lane runs them as soon as its previous cycle
+ * is written, and the room check for the samples can use the ACTUAL period instead of the
+ * worst case 1.2*P. */
+__device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDiag &dg)
 {
   VS_DIAG_ADD(dg, 7)
   /* ---- jitter: fg:248-291 ---- */
@@ -218,7 +217,33 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
       if (!((Amplitude > c.a_hi) || (Amplitude < c.a_lo))) break;
     }
   }
+  s.amp_next = Amplitude;
+  s.S_next = S;
+  s.pend = true;
+  VS_DIAG_ADD(dg, 0)
+}
 
+/*
+ * Second half of a cycle, for every lane that is ACTIVE in the EXEC mask (the caller wraps the
+ * call in "if (want)"): the samples -- statement-by-statement restatement of
+ * flowgen_shimmer.c:317-423 (scalar form: oracle/vs_oracle.c).  Plain SIMT code: loops have
+ * per-lane trip counts and the hardware masks lanes that are done; because all lanes walk the
+ * same phase of their own cycle together the masks are nearly full.  Within a loop trip the
+ * samples are computed stage by stage so that independent dependency chains interleave (one
+ * wavefront per SIMD issues a dependent instruction every ~8 ticks, an independent one every
+ * ~5: tools/ubench).
+ * ltab is this wavefront's copy of the cos rows in LDS, c.tab_off the lane's row in it.
+ */
+template <bool LOG, bool PUB = false>
+__device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t *ring, int C,
+                                              int lane, int N, const double *ltab,
+                                              vs_cycle_rec *logrow, int log_cap, VsDiag &dg,
+                                              int *gpub_lane = nullptr)
+{
+  VS_DIAG_ADD(dg, 7)
+  const float Amplitude = s.amp_next;
+  const float S = s.S_next;
+  s.pend = false;
   VS_DIAG_ADD(dg, 0)
   const int T = s.T;
   const int T2 = c.T2;
@@ -324,6 +349,14 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
   }
 
   VS_DIAG_ADD(dg, 2)
+  if (PUB && !(((c.flags & VS_DF_NOISE) != 0) && T4 > 0)) {
+    /* wave-specialised kernel: the open phase [0, T3) is in the ring -- let the filter wave have
+     * it while the closed phase is still being written (the LDS keeps this store behind the
+     * ring writes above).  Not when noise will still be added to [0, T4) below. */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __hip_atomic_store(gpub_lane, s.g + ((T3 < lim) ? T3 : lim), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
   float x_pow = 0.0f, w_pow = 0.0f;
   const bool noisy = (c.flags & VS_DF_NOISE) != 0;
 
@@ -393,6 +426,12 @@ __device__ __forceinline__ void vs_generate_cycle(const VsCfg &c, VsGen &s, int1
           ring[(ok ? slot : C) * VS_WAVE + lane] = (int16_t)xv;
         }
         q0 += 8;
+        if (PUB) {
+          const int done = (q0 < mlim) ? q0 : mlim; /* noise samples [T3, T3 + done) are written */
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     } else {
       /* general case: draws cover [0,T4) then [T3,T) */
@@ -549,6 +588,7 @@ __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsC
   s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
   s.dp0 = 0.0f; s.ds0 = 0.0f;
   s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
+  s.amp_next = 0.0f; s.S_next = 0.0f; s.pend = false;
 }
 
 /* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its lanes
@@ -635,12 +675,13 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
     bool ready = live;
     if (KIND != VS_KIND_FILTER) {
       ready = live && ((s.g - n >= VS_SS) || (s.g >= N));
-      const bool want = live && (s.g < N) && (s.g - n + c.tbound <= C);
+      if (live && (s.g < N) && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
+      const bool want = live && s.pend && (s.g - n + s.T <= C);
       const int n_live = __builtin_popcountll(__ballot(live));
       const int n_ready = __builtin_popcountll(__ballot(ready));
       const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * args.ready_min) || !__any(want));
       if (!filter_now) {
-        if (want) vs_generate_cycle<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
+        if (want) vs_cycle_emit<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
         continue;
       }
     }
@@ -714,6 +755,9 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  * the launch is set and the wave leaves) so that a protocol bug cannot hang the device.
  */
 #define VS_SPIN_LIMIT (1 << 22)
+#ifndef VS_POLL_SLEEP
+#define VS_POLL_SLEEP 8 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one */
+#endif
 
 template <int ARITH>
 __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArgs args)
@@ -759,18 +803,19 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
     for (;;) {
       const bool need = valid && (s.g < N);
       if (!__any(need)) break;
+      if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
       const int n_seen = __hip_atomic_load(&npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const bool want = need && (s.g - n_seen + c.tbound <= C);
-      const bool hungry = want && (s.g - n_seen < 2 * VS_SS); /* its filter is about to run dry */
+      const bool want = need && (s.g - n_seen + s.T <= C);
+      const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
       const int n_need = __builtin_popcountll(__ballot(need));
       const int n_want = __builtin_popcountll(__ballot(want));
       if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
-        if (want) vs_generate_cycle<false>(c, s, ring, C, lane, N, ltab, nullptr, 0, dg);
+        if (want) vs_cycle_emit<false, true>(c, s, ring, C, lane, N, ltab, nullptr, 0, dg, &gpub[lane]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(&gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         spins = 0;
       } else {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
         VS_DIAG_ADD(dg, 6)
         if (++spins > VS_SPIN_LIMIT) {
           if (args.err && lane == 0) atomicOr(args.err, 1);
@@ -828,7 +873,7 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
         spins = 0;
         VS_DIAG_ADD(dg, 0)
       } else {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
         VS_DIAG_ADD(dg, 6)
         if (++spins > VS_SPIN_LIMIT) {
           if (args.err && lane == 0) atomicOr(args.err, 2);
