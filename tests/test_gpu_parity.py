@@ -99,3 +99,25 @@ def test_both_fused_kernels_bit_exact(monkeypatch, kernel):
             assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("kernel", ["single", "ws"])
+def test_noise_below_t4_is_never_consumed_early(monkeypatch, kernel):
+    """-l gives a DC flow > 0, so the noise also covers [0, T4) of every cycle and is added to
+    samples that were written earlier in the same cycle.  The wave-specialised kernel publishes
+    its progress inside a cycle; it must not hand those samples to the filter wave before the
+    noise is in (a race that showed as a rare mismatch before it was fenced off)."""
+    monkeypatch.setenv("VS_KERNEL", kernel)
+    fa = ["-r", "16000", "-d", "0.5", "-j", "3", "-s", "10", "-n", "5", "-z", "0.5", "-l", "0.1"]
+    lanes = []
+    for seed in range(700):
+        lane, dur = vs.lane_from_cli(fa, ["-v", "u", "-g", "1"], 5000 + seed)
+        lanes.append(lane)
+    ns = vs.num_samples(16000, dur)
+    eng = vs.Engine(0)
+    try:
+        for _ in range(3):
+            got = eng.synth(lanes, ns)
+            assert np.array_equal(got, po.synth(lanes, ns))
+    finally:
+        eng.close()
