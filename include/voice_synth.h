@@ -164,6 +164,10 @@ void vs_ctx_destroy(vs_ctx *ctx);
 int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream);
 int vs_ctx_set_arith(vs_ctx *ctx, int arith);
 int vs_ctx_last_hip_error(const vs_ctx *ctx);
+/* Device self-test of the arithmetic shortcuts the kernels take (exhaustive over all 2^31
+ * draws for the division shortcut; Philox known answers; integer square root; rounding).
+ * failures (optional) receives four counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
+int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures);
 /* Name, CU count of the device in use. */
 int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count);
 

@@ -121,3 +121,10 @@ def test_noise_below_t4_is_never_consumed_early(monkeypatch, kernel):
             assert np.array_equal(got, po.synth(lanes, ns))
     finally:
         eng.close()
+
+
+def test_device_selftest(engine):
+    """exhaustive on the device: the 3-instruction division shortcut equals IEEE division for
+    all 2^31 draws; Philox known answer; integer square root; round2int against the literal form"""
+    rc, fails = engine.selftest()
+    assert rc == 0 and fails == [0, 0, 0, 0], fails

@@ -167,6 +167,12 @@ class Engine:
     def synchronize(self):
         check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
 
+    def selftest(self):
+        """(rc, [division shortcut, philox, isqrt, round2int] failure counts)"""
+        f = (C.c_uint64 * 4)()
+        rc = self._lib.vs_ctx_selftest(self._ctx, f)
+        return rc, [int(v) for v in f]
+
     def device_info(self):
         name = C.create_string_buffer(128)
         cu = C.c_int()

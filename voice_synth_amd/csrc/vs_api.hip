@@ -27,6 +27,7 @@
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
 
+extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
 extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
 extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
@@ -124,6 +125,26 @@ extern "C" int vs_ctx_synchronize(vs_ctx *ctx)
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VS_OK;
+}
+
+extern "C" int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
+{
+  if (!ctx) return VS_ERR_ARG;
+  unsigned long long *d = nullptr, h[4] = {0, 0, 0, 0};
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipMalloc((void **)&d, sizeof(h)));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(h), ctx->stream);
+  if (e == hipSuccess) e = vs_launch_selftest(d, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    return VS_ERR_HIP;
+  }
+  if (failures)
+    for (int k = 0; k < 4; k++) failures[k] = h[k];
+  return (h[0] | h[1] | h[2] | h[3]) ? VS_ERR_INTERNAL : VS_OK;
 }
 
 extern "C" int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr)

@@ -943,6 +943,79 @@ extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t 
   return hipGetLastError();
 }
 
+/*
+ * Device self-test (vs_ctx_selftest): the shortcuts this file takes instead of the reference's
+ * library calls are checked against the straightforward form ON THE DEVICE.
+ *   [0] vs_unit_of_draw(r) == (double)r / 2147483647.0 (the compiler's IEEE division) for ALL
+ *       2^31 possible draws;
+ *   [1] Philox4x32-10 known answers (Random123 kat_vectors) and the counter/key wiring;
+ *   [2] vs_isqrt_floor(v) == floor(sqrt(v)) for float-valued v on a grid that includes every
+ *       perfect square up to 2^24 and its two float neighbours;
+ *   [3] vs_round2int(x) against a literal transcription of vowel_new.c:413-427 on a grid around
+ *       every half-integer and the clamp edges.
+ * bad[k] counts failures of check k.
+ */
+__device__ __forceinline__ int vs_round2int_literal(double x)
+{
+  double dec = x - floor(x);
+  if (dec > 0.5) x = x + 1;
+  if (x > 32767) x = 32767;
+  else if (x < -32767) x = -32767;
+  return (int)(int16_t)(int)floor(x);
+}
+
+__global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *bad)
+{
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  const unsigned long long nthreads = (unsigned long long)gridDim.x * 256ull;
+  unsigned long long b0 = 0, b2 = 0, b3 = 0;
+  for (unsigned long long r = tid; r < (1ull << 31); r += nthreads) {
+    const double ref = (1.0 * (double)(uint32_t)r) / 2147483647.0;
+    if (vs_unit_of_draw((uint32_t)r) != ref) b0++;
+  }
+  for (unsigned long long k = tid; k < (1ull << 24); k += nthreads) {
+    const float sq = (float)((double)k * (double)k);
+    const uint32_t sb = __float_as_uint(sq); /* sq >= 0: neighbours are the adjacent bit patterns */
+    const float cand[3] = {sq, __uint_as_float(sb > 0u ? sb - 1u : 0u), __uint_as_float(sb + 1u)};
+    for (int j = 0; j < 3; ++j) {
+      const double v = (double)cand[j];
+      long long want = (long long)k - 2;
+      if (want < 0) want = 0;
+      while ((double)(want + 1) * (double)(want + 1) <= v) ++want; /* floor(sqrt(v)) by definition */
+      if ((long long)vs_isqrt_floor(v) != want) b2++;
+    }
+  }
+  for (unsigned long long k = tid; k < 140000ull * 64ull; k += nthreads) {
+    const int base = (int)(k / 64ull) - 70000;             /* integers -70000 .. 69999 */
+    const int j = (int)(k % 64ull);
+    const double frac = (j < 32) ? 0.5 + (double)(j - 16) * 0x1p-50 : (double)(j - 32) / 32.0;
+    const double x = (double)base + frac;
+    if (vs_round2int(x) != vs_round2int_literal(x)) b3++;
+  }
+  if (b0) atomicAdd(&bad[0], b0);
+  if (b2) atomicAdd(&bad[2], b2);
+  if (b3) atomicAdd(&bad[3], b3);
+  if (tid == 0) {
+    unsigned long long b1 = 0;
+    uint32_t o0, o1, o2, o3;
+    vs_philox(0u, 0u, 0u, o0, o1, o2, o3);
+    if (o0 != 0x6627E8D5u || o1 != 0xE169C58Du || o2 != 0xBC57AC4Cu || o3 != 0x9B00DBD8u) b1++;
+    /* counter (n, 0, 0, 0) with a non-trivial key against the host-computed value is covered by
+     * every bit-exact parity test; here: the key words are not swapped */
+    vs_philox(1u, 2u, 3u, o0, o1, o2, o3);
+    uint32_t p0, p1, p2, p3;
+    vs_philox(1u, 3u, 2u, p0, p1, p2, p3);
+    if (o0 == p0 && o1 == p1) b1++;
+    if (b1) atomicAdd(&bad[1], b1);
+  }
+}
+
+extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream)
+{
+  hipLaunchKernelGGL(vs_selftest_kernel, dim3(4096), dim3(256), 0, stream, bad_dev);
+  return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------------------------------
  * launch table
  * ---------------------------------------------------------------------------------------- */
