@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
                  bounded sample of the same workload -- rank 0, N = 1 only;
   gather       : N > 1 only -- the RCCL delivery of all PCM to rank 0, timed on its own AFTER
                  the timed region (it is not part of `value`).
+The only use of oracle/ is inside cpu_baseline(): the CPU port is timed there, and its first
+rows are compared with the rows the GPU produced in the timed region.
 """
 import argparse
 import json
@@ -52,8 +54,11 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(specs_fn, n_samples, target_s):
-    """The CPU oracle on a bounded sample of the same workload, all host cores."""
+def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
+    """The CPU oracle on a bounded sample of the same workload, all host cores.  The sample
+    starts at lane 0, so its first rows double as a parity spot check of what the GPU just
+    produced (the only place bench.py touches oracle/)."""
+    import numpy as np
     import voice_synth_amd as vs
     from oracle import pyoracle as po
 
@@ -69,9 +74,9 @@ def cpu_baseline(specs_fn, n_samples, target_s):
     n_lanes = (n_lanes // cores) * cores or cores
     lanes, _ = vs.lanes_from_specs(specs_fn(n_lanes))
     t0 = time.perf_counter()
-    po.synth(lanes, n_samples, threads=cores)
+    pcm = po.synth(lanes, n_samples, threads=cores)
     t = time.perf_counter() - t0
-    return {
+    out = {
         "value": round(n_lanes * n_samples / t / 1e6, 2),
         "unit": "Msamples/s",
         "cores": cores,
@@ -79,6 +84,11 @@ def cpu_baseline(specs_fn, n_samples, target_s):
         "sample": "%d utterances x %d samples of the same workload (first lanes), %.1f s, OpenMP over lanes"
                   % (n_lanes, n_samples, t),
     }
+    if gpu_first_lanes is not None:
+        k = min(len(gpu_first_lanes), n_lanes)
+        out["gpu_rows_checked"] = k
+        out["gpu_mismatched_samples"] = int((gpu_first_lanes[:k] != pcm[:k]).sum())
+    return out
 
 
 def main():
@@ -156,14 +166,8 @@ def main():
     samples_per_step = per_gpu * n_samples * world
     value = samples_per_step * args.steps / elapsed / 1e6
 
-    # ---- parity spot check of what was just timed (first lanes of this rank) ----
-    check = None
-    if rank == 0:
-        from oracle import pyoracle as po
-        ncheck = min(4, per_gpu)
-        got = out[:ncheck, :n_samples].cpu().numpy()
-        want = po.synth([lanes[i] for i in range(ncheck)], n_samples, threads=1)
-        check = {"lanes": ncheck, "mismatched_samples": int((got != want).sum())}
+    # first rows of what was just timed, for the spot check inside the cpu_baseline leg
+    first_rows = out[:min(64, per_gpu), :n_samples].cpu().numpy() if rank == 0 else None
 
     # ---- the other arithmetic mode, outside the timed region (3 launches) ----
     other = vs.VS_ARITH_FMA if arith == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
@@ -246,14 +250,14 @@ def main():
             "other_arith": {"arith": "fma" if arith == vs.VS_ARITH_EXACT else "exact",
                             "kernel_ms_avg": round(other_ms, 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
-            "parity_check": check,
             "device": dev_name.strip(),
         }
         if gather:
             result["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(
-                lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples, args.cpu_seconds)
+                lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples, args.cpu_seconds,
+                first_rows)
         print(json.dumps(result), flush=True)
 
     plan.close()
