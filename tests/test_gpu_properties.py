@@ -136,3 +136,58 @@ def test_mixed_batch_every_option_combination(engine):
     got = engine.synth(lanes, n)
     want = po.synth(lanes, n)
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_random_parameter_fuzz(engine):
+    """600 lanes with randomly drawn command lines over the whole option space the reference
+    accepts (seeded): rates, F0/Fg, closed quotient, closure speed and its variation, jitter up
+    to the 10 % limit, shimmer, SNR, DC flow, amplitude, every vowel table, gain, pre-emphasis,
+    output noise.  One batch, bit-exact against the oracle."""
+    rng = np.random.default_rng(424242)
+    lanes = []
+    tries = 0
+    while len(lanes) < 600:
+        tries += 1
+        fs = int(rng.choice([8000, 11025, 16000, 32000, 44100]))
+        f0 = float(rng.uniform(60, 400))
+        fg = f0 * float(rng.uniform(1.01, 1.5)) + 0.5
+        fa = ["-r", str(fs), "-d", "0.5", "-f", "%.2f" % f0, "-g", "%.2f" % fg]
+        if rng.random() < 0.6:
+            fa += ["-j", "%.2f" % rng.uniform(0, 10)]
+        if rng.random() < 0.6:
+            fa += ["-s", "%.2f" % rng.uniform(0, 30)]
+        if rng.random() < 0.6:
+            fa += ["-n", "%.1f" % rng.uniform(0, 50)]
+        if rng.random() < 0.3:
+            fa += ["-l", "%.3f" % rng.uniform(0, 0.29)]
+        if rng.random() < 0.5:
+            fa += ["-z", "%.2f" % rng.uniform(0, 1)]
+        if rng.random() < 0.5:
+            fa += ["-k", "%.2f" % rng.uniform(0.5, 1.2)]
+        if rng.random() < 0.5:
+            fa += ["-c", "%.2f" % rng.uniform(0.05, 1.0)]
+        if rng.random() < 0.5:
+            fa += ["-a", str(int(rng.integers(1, 32766)))]
+        va = ["-v", str(rng.choice(list("aiu1234567")))]
+        if rng.random() < 0.5:
+            va += ["-g", "%.2f" % rng.uniform(1, 20)]
+        if rng.random() < 0.5:
+            va += ["-p", "%.2f" % rng.uniform(0, 1)]
+        if rng.random() < 0.3:
+            va += ["-n", "%.1f" % rng.uniform(1, 40)]
+        try:
+            lane, dur = vs.lane_from_cli(fa, va, int(rng.integers(0, 2**63)))
+        except vs.VsError:
+            continue                      # the reference would answer usage(), e.g. F0 < 50 after rounding
+        if vs.load().vs_lane_validate(C.byref(lane)) != 0:
+            continue
+        if int(np.float32(lane.fs) / np.float32(lane.F0)) * 1.2 > 500:
+            continue                      # long periods next to 64 different cos rows exceed the LDS (tested separately)
+        lanes.append(lane)
+    n = 6000
+    got = engine.synth(lanes, n)
+    want = po.synth(lanes, n)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, "lanes %s differ" % bad[:10]
+    flow = engine.source(lanes, n)
+    assert np.array_equal(flow, po.source(lanes, n))
