@@ -186,17 +186,25 @@ def main():
     # ---- N > 1: delivery of the PCM to rank 0 over RCCL, timed on its own ----
     gather = None
     if world > 1 and not args.no_gather:
-        launch()
-        sync_all()
-        local = out[:, :n_samples]
-        g0 = time.perf_counter()
-        full_pcm = gather_pcm(local, per_gpu * world, dst=0)
-        sync_all()
-        g = time.perf_counter() - g0
-        nbytes = per_gpu * (world - 1) * n_samples * 2
-        gather = {"ms": round(g * 1e3, 3), "GB/s": round(nbytes / g / 1e9, 1),
-                  "bytes_into_rank0": nbytes, "included_in_value": False}
-        del full_pcm
+        # optional delivery step: it must never cost the benchmark line, so failures are reported
+        try:
+            launch()
+            sync_all()
+            local = out[:, :n_samples]
+            g0 = time.perf_counter()
+            full_pcm = gather_pcm(local, per_gpu * world, dst=0)
+            sync_all()
+            g = time.perf_counter() - g0
+            nbytes = per_gpu * (world - 1) * n_samples * 2
+            gather = {"ms": round(g * 1e3, 3), "GB/s": round(nbytes / g / 1e9, 1),
+                      "bytes_into_rank0": nbytes, "included_in_value": False}
+            if rank == 0:
+                # every shard arrived where it belongs: rank r's first row is row r*per_gpu of the result
+                ok = bool(torch.equal(full_pcm[:1], local[:1]))
+                gather["rank0_block_intact"] = ok
+            del full_pcm
+        except Exception as exc:  # pragma: no cover - depends on the node's RCCL
+            gather = {"error": "%s: %s" % (type(exc).__name__, exc), "included_in_value": False}
 
     result = None
     if rank == 0:
