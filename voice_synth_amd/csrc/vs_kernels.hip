@@ -27,7 +27,8 @@
  * double state is bit-identical to the C reference; VS_ARITH_FMA is the explicit, opt-in
  * fused variant.  IEEE fp64 mul/add/fma/div and fp32 mul/add/div are correctly rounded on
  * gfx950 (HIP's default -fhip-fp32-correctly-rounded-divide-sqrt is kept); cos() values come
- * from the host libm table; sqrt() is only used under an integer fix-up.
+ * from the host libm table; the device sqrt() only seeds an exact fix-up (an integer search in
+ * the source, one exact Newton test in the output-noise kernel).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
 /*
  * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts of one
- * 128-thread workgroup -- wave 0 only generates (vs_generate_cycle), wave 1 only filters
+ * 128-thread workgroup -- wave 0 only generates (vs_cycle_scalars + vs_cycle_emit), wave 1 only filters
  * (vs_superstep) -- coupled through the LDS ring and two per-lane progress words.
  *
  * Why: at batch 65536 the one-wave kernel leaves exactly one wavefront per SIMD, and one
@@ -901,6 +902,21 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
  * kernel, 8 bytes in and out per thread, HBM-bound.  Lframe is a multiple of 100 (milisec1 is
  * even), so four consecutive samples never straddle a frame.
  */
+/* sqrt(v) correctly rounded to double whatever the last bit of the device sqrt: s is at most
+ * one ulp off, the residual r = v - s*s is exact in one fma, and the true root lies beyond
+ * s + ulp/2 exactly when r > s*ulp (a root of a double is never a rounding midpoint). */
+__device__ __forceinline__ double vs_sqrt_rn(double v)
+{
+  double s = sqrt(v);
+  if (!(v > 0.0) || !(s > 0.0)) return s;
+  const double r = __builtin_fma(-s, s, v);
+  const double up = __longlong_as_double(__double_as_longlong(s) + 1) - s; /* ulp above s */
+  const double dn = s - __longlong_as_double(__double_as_longlong(s) - 1); /* ulp below s */
+  if (r > s * up) s = s + up;
+  else if (-r > s * dn) s = s - dn;
+  return s;
+}
+
 __global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args, long quads_per_lane)
 {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -920,7 +936,7 @@ __global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args, lo
   const int left = N - fr * Lframe;
   const int ni = (left < Lframe) ? left : Lframe;
   const float sig_power = args.opow[row * args.opow_pitch + fr] / (float)ni;
-  const float ndw = (float)sqrt((double)(12.0f * sig_power / snr));
+  const float ndw = (float)vs_sqrt_rn((double)(12.0f * sig_power / snr));
   uint32_t o[4];
   vs_philox((uint32_t)qd, L->okey0, L->okey1, o[0], o[1], o[2], o[3]);
 #pragma unroll
