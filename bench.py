@@ -84,6 +84,20 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         "sample": "%d utterances x %d samples of the same workload (first lanes), %.1f s, OpenMP over lanes"
                   % (n_lanes, n_samples, t),
     }
+    if po.have_reference():
+        # the reference AS SHIPPED (oracle/_ref: its own two programs, -O0, one process pair per
+        # utterance through .wav files, Philox shim), one core, a handful of utterances
+        specs = specs_fn(8)
+        t0 = time.perf_counter()
+        for fa, va, seed in specs:
+            ref = po.run_reference(fa, va, seed)
+        tr = time.perf_counter() - t0
+        out["reference_as_shipped"] = {
+            "value": round(len(specs) * n_samples / tr / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+            "sample": "%d utterances through oracle/_ref/flowgen_shimmer | vowel (-O0, file I/O and process start included), %.2f s"
+                      % (len(specs), tr),
+            "last_utterance_matches_port": bool(np.array_equal(ref["pcm"], pcm[len(specs) - 1])),
+        }
     if gpu_first_lanes is not None:
         k = min(len(gpu_first_lanes), n_lanes)
         out["gpu_rows_checked"] = k
