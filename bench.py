@@ -102,6 +102,11 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         k = min(len(gpu_first_lanes), n_lanes)
         out["gpu_rows_checked"] = k
         out["gpu_mismatched_samples"] = int((gpu_first_lanes[:k] != pcm[:k]).sum())
+        # BASELINE.json's second figure: RMS error against the C reference path for identical
+        # seeds, in int16 LSB and on the /32768 scale (north star: <= 1e-5 normalised)
+        d = gpu_first_lanes[:k].astype(np.float64) - pcm[:k].astype(np.float64)
+        out["gpu_rms_error_lsb"] = float(np.sqrt(np.mean(d * d)))
+        out["gpu_rms_error_normalised"] = float(np.sqrt(np.mean((d / 32768.0) ** 2)))
     return out
 
 

@@ -128,3 +128,23 @@ def test_device_selftest(engine):
     all 2^31 draws; Philox known answer; integer square root; round2int against the literal form"""
     rc, fails = engine.selftest()
     assert rc == 0 and fails == [0, 0, 0, 0], fails
+
+
+@pytest.mark.parametrize("index,n", [(2, 64), (3, 130), (4, 40), (5, 100)])
+def test_every_config_at_unit_gain(engine, index, n):
+    """the default gain 10 clips heavily (the rounding clamp hides differences in
+    the clipped samples); every configuration is therefore also checked at the minimum gain 1,
+    where far fewer samples clip, in both arithmetic modes."""
+    lanes, ns = _lanes(index, n)
+    for l in range(n):
+        lanes[l].gain = 1.0
+    want = po.synth(lanes, ns)
+    engine.set_arith(vs.VS_ARITH_EXACT)
+    assert np.array_equal(engine.synth(lanes, ns), want)
+    engine.set_arith(vs.VS_ARITH_FMA)
+    try:
+        got = engine.synth(lanes, ns)
+    finally:
+        engine.set_arith(vs.VS_ARITH_EXACT)
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    assert _rms_norm(got, want) <= TOL_RMS_NORMALISED
