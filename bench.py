@@ -210,6 +210,14 @@ def main():
             launch()
             sync_all()
             local = out[:, :n_samples]
+            # every rank must take the same decision, or the peers would wait for a root that
+            # gave up: rank 0 checks that the gathered PCM fits, the verdict is all-reduced
+            need = per_gpu * world * n_samples * 2 + (1 << 30)
+            fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0],
+                                dtype=torch.int32, device=dev)
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+            if int(fits.item()) == 0:
+                raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
             g0 = time.perf_counter()
             full_pcm = gather_pcm(local, per_gpu * world, dst=0)
             sync_all()

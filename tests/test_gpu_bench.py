@@ -3,6 +3,7 @@ cpu_baseline; and the torch.distributed.run launch path (world size 1 here: RCCL
 all-reduce of the timings are exercised; more ranks are the driver's to launch)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -34,9 +35,17 @@ def test_bench_single_process_small():
     assert d["cpu_baseline"]["gpu_rows_checked"] >= 1 and d["cpu_baseline"]["gpu_mismatched_samples"] == 0
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_bench_under_torch_distributed_run():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--lanes", "4096", "--steps", "3",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--lanes", "4096", "--steps", "3",
            "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
