@@ -247,7 +247,7 @@ def main():
                 traffic = None
         tflops = FLOP_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e12
         result = {
-            "metric": "synthesised Msamples/s (whole node)",
+            "metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref",
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
