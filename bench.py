@@ -290,9 +290,14 @@ def main():
         if gather:
             result["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(
-                lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples, args.cpu_seconds,
-                first_rows)
+            cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples,
+                              args.cpu_seconds, first_rows)
+            result["cpu_baseline"] = cb
+            # the metric's second figure, next to the throughput
+            result["rms_vs_c_ref"] = {"lsb": cb.get("gpu_rms_error_lsb"),
+                                      "normalised": cb.get("gpu_rms_error_normalised"),
+                                      "rows_checked": cb.get("gpu_rows_checked"),
+                                      "tolerance_normalised": 1e-5}
         print(json.dumps(result), flush=True)
 
     plan.close()
