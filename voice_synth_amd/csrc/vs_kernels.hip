@@ -504,19 +504,26 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
                                              int16_t *__restrict__ orow, int n, int N, bool vec_ok,
-                                             int (&outv)[VS_SS])
+                                             int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8])
 {
   int xin[VS_SS];
   if (KIND == VS_KIND_FILTER) {
     if (vec_ok && (n + VS_SS <= N)) {
+      /* xnext[] holds this super-step's 48 bytes, loaded one super-step ago; the loads for the
+       * next one are issued now and complete behind the ~1400 instructions below (with one
+       * wave per SIMD nothing else hides an HBM round trip) */
 #pragma unroll
       for (int k = 0; k < VS_SS / 8; ++k) {
-        const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * k);
+        const vs_u32x4 v = xnext[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
           xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
         }
+      }
+      if (n + 2 * VS_SS <= N) {
+#pragma unroll
+        for (int k = 0; k < VS_SS / 8; ++k) xnext[k] = *(const vs_u32x4 *)(irow + n + VS_SS + 8 * k);
       }
     } else {
 #pragma unroll
@@ -661,6 +668,11 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
   dg.t = vs_stamp();
 #endif
+  vs_u32x4 xpre[VS_SS / 8]; /* filter-only kind: the next super-step's input, loaded ahead */
+  if (KIND == VS_KIND_FILTER && valid && args.vec_ok && VS_SS <= N) {
+#pragma unroll
+    for (int k = 0; k < VS_SS / 8; ++k) xpre[k] = *(const vs_u32x4 *)(irow + 8 * k);
+  }
   float fsum = 0.0f; /* vowel -n: running sum of y^2 of the current frame */
   int fpos = 0, fidx = 0;
   const int Lframe = L->Lframe;
@@ -691,7 +703,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
     if (ready) {
       int outv[VS_SS];
       vs_superstep<ARITH, KIND>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
-                                args.vec_ok != 0, outv);
+                                args.vec_ok != 0, outv, xpre);
       if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
         if (rslot >= C) rslot = 0;
@@ -861,8 +873,9 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
       if ((n_ready > 0) && (n_ready * 64 >= n_live * args.ready_min)) {
         if (ready) {
           int outv[VS_SS];
+          vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
           vs_superstep<ARITH, VS_KIND_SYNTH>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
-                                             orow, n, N, args.vec_ok != 0, outv);
+                                             orow, n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
