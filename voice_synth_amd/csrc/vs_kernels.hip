@@ -89,7 +89,7 @@ __device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1
 /* per-lane constants */
 struct VsCfg {
   float jitter, shimmer, K, Kvar, DC, noise, t_hi, t_lo, a_hi, a_lo;
-  int amp, P, T2, tab_off, tbound, dcs;
+  int amp, P, T2, tab_off, dcs;
   uint32_t flags, key0, key1;
 };
 
@@ -591,7 +591,7 @@ __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsC
   c.DC = L->DC; c.noise = L->noise; c.t_hi = L->t_hi; c.t_lo = L->t_lo;
   c.a_hi = L->a_hi; c.a_lo = L->a_lo;
   c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = 0;
-  c.tbound = L->tbound; c.dcs = L->dcs;
+  c.dcs = L->dcs;
   c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
   s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
   s.dp0 = 0.0f; s.ds0 = 0.0f;
@@ -744,15 +744,15 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 }
 
 /*
- * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts of one
- * 128-thread workgroup -- wave 0 only generates (vs_cycle_scalars + vs_cycle_emit), wave 1 only filters
- * (vs_superstep) -- coupled through the LDS ring and two per-lane progress words.
+ * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts -- one only
+ * generates (vs_cycle_scalars + vs_cycle_emit), the other only filters (vs_superstep) -- coupled
+ * through the LDS ring and two per-lane progress words.  A workgroup holds one or two such pairs.
  *
- * Why: at batch 65536 the one-wave kernel leaves exactly one wavefront per SIMD, and one
- * wavefront can issue a VALU instruction only every ~4 cycles (tools/ubench: an fp64
- * instruction costs 5.3 ticks with one wave per SIMD, 3.6 with two; an integer one 5.3 vs
- * 2.7) and exposes every LDS / dependency stall.  Two waves per 64 utterances put two waves
- * on every SIMD without needing more utterances.
+ * When: the plan picks it for grids that leave at least half of the chip's SIMDs empty (e.g.
+ * BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024 SIMDs).
+ * Every wavefront then has a SIMD of its own and a launch takes max(generator, filter) instead
+ * of their sum (1.35-1.6x).  On a full grid it would put two waves on
+ * every SIMD; measured, that is no faster than the one-wave kernel, which stays the default.
  *
  * Hand-off (workgroup scope, LDS only):
  *   gpub[l] = samples lane l's generator has written to the ring   (written by wave 0)
@@ -760,7 +760,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  * The LDS executes one wavefront's operations in order, so "ring writes, then gpub" on one
  * side and "gpub read, then ring reads" on the other is a release/acquire pair; the fences
  * below keep the compiler from reordering.  Wave 0 writes slots of [g, g+T) only when
- * g - npub + tbound <= C, i.e. never over samples the filter has not consumed.
+ * g - npub + T <= C (T = the cycle's period, fixed by vs_cycle_scalars), i.e. never over
+ * samples the filter has not consumed.
  *
  * Progress: a lane that is short of 24 samples always has room for its next cycle, and wave 0
  * generates whenever such a lane exists; if no lane has room every lane holds more than 24
