@@ -32,7 +32,8 @@ def main():
             plan.launch(kind, out); eng.synchronize()
             a = eng.dev_download(dg, (grid, 8), np.uint64).astype(np.float64)
             tot = a.sum(axis=1)
-            print("%s/%s: cycles per wave %.3e (per sample %.0f)" % (name, kname, tot.mean(), tot.mean() / ns))
+            print("%s/%s: cycles per wave %.3e (per sample %.0f); over waves: min %.3e p50 %.3e p99 %.3e max %.3e" %
+                  (name, kname, tot.mean(), tot.mean() / ns, tot.min(), np.percentile(tot, 50), np.percentile(tot, 99), tot.max()))
             for k in range(8):
                 print("    %-18s %6.1f%%   %7.1f cycles/sample" % (NAMES[k], 100 * a[:, k].mean() / tot.mean(), a[:, k].mean() / ns))
 main()
