@@ -12,7 +12,8 @@
  * integers.  No function calls exit(); every failure is a negative return code.
  *
  * Threading: a vs_ctx and the plans made from it may be used by one thread at a time.
- * Different contexts are independent.  There is no global mutable state.
+ * Different contexts are independent.  There is no global mutable state, and the library
+ * reads no environment variable after vs_ctx_create() (see vs_ctx_set_tuning()).
  *
  * There is no CPU fallback: if no gfx950 device is usable, vs_ctx_create() fails with
  * VS_ERR_NODEVICE and nothing can be synthesised.
@@ -165,9 +166,34 @@ void vs_ctx_destroy(vs_ctx *ctx);
 int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream);
 int vs_ctx_set_arith(vs_ctx *ctx, int arith);
 int vs_ctx_last_hip_error(const vs_ctx *ctx);
-/* Device self-test of the arithmetic shortcuts the kernels take (exhaustive over all 2^31
- * draws for the division shortcut; Philox known answers; integer square root; rounding).
- * failures (optional) receives four counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
+
+/* Launch tuning.  All zero (the default) = the library's own choices; the fields exist for
+ * measurements (tools/) and tests.  Values are validated here, once, and copied into every plan
+ * made afterwards; nothing else can change what a plan launches -- in particular no environment
+ * variable does, unless VS_DEBUG_TUNING=1 asks vs_ctx_create() to read the experiment knobs
+ * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_GEN_LOW, VS_GEN_MIN) through this
+ * same function.  NULL resets. */
+#define VS_KERNEL_AUTO 0
+#define VS_KERNEL_SINGLE 1 /* one wavefront per 64 utterances generates and filters */
+#define VS_KERNEL_WS 2     /* wave-specialised: a generator and a filter wavefront per 64 utterances */
+#define VS_FAULT_WITHHOLD_PROGRESS 1 /* tests: the generator wavefront never publishes its progress */
+typedef struct vs_tuning {
+  int32_t kernel;     /* VS_KERNEL_* */
+  int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */
+  int32_t ready_min;  /* 1..64: a super-step runs when ready lanes * 64 >= live lanes * ready_min */
+  int32_t ws_pairs;   /* 1 or 2 generator/filter pairs per workgroup (2 only if both fit the LDS) */
+  int32_t gen_low;    /* >= 24: a lane with fewer buffered samples starts a generator round at once */
+  int32_t gen_min;    /* 1..64: a round starts when wanting lanes * 64 >= needing lanes * gen_min */
+  int32_t spin_limit; /* polls before a waiting wavefront gives up with VS_ERR_INTERNAL */
+  int32_t fault;      /* VS_FAULT_* */
+} vs_tuning;
+int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
+/* Device self-test of the arithmetic shortcuts the kernels take: [0] division shortcut
+ * (exhaustive over all 2^31 draws), [1] Philox known answers, [2] integer square root,
+ * [3] rounding, [4] one-fma noise sample (exhaustive over the draws at 16 widths), [5] two-block
+ * Philox with prepared round keys.  failures (optional) receives VS_SELFTEST_COUNTERS
+ * counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
+#define VS_SELFTEST_COUNTERS 6
 int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures);
 /* Name, CU count of the device in use. */
 int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count);
@@ -206,7 +232,9 @@ int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples
 /* fg:246-423; flow is int16 [n_lanes][n_samples].  recs/ncyc optional (NULL). */
 int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *flow,
               vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc);
-/* vw:237-331; only gain, pre_emphasis, vowel/A of each lane are used. */
+/* vw:237-331; only gain, pre_emphasis, vowel/A, out_snr/out_seed and fs (frame length of the
+ * output noise) of each lane are used; the source fields are not even validated, so a flow of
+ * any sample rate can be filtered (vowel_new.c:196-205). */
 int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
               const int16_t *flow, int16_t *pcm);
 

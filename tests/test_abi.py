@@ -18,7 +18,7 @@ def declared_functions():
 
 def test_every_declared_symbol_is_exported_and_bound():
     names = declared_functions()
-    assert len(names) >= 31
+    assert len(names) >= 32
     lib = C.CDLL(_ffi.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), "libvoicesynth.so does not export %s" % n
@@ -29,7 +29,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_sizes_match_the_header():
     assert C.sizeof(_ffi.Lane) == 9 * 4 + 3 * 4 + 8 + 4 * 4 + 23 * 8 + 8   # 264 bytes
     assert C.sizeof(_ffi.CycleRec) == 16
-    assert C.sizeof(_ffi.DevLane) == 288
+    assert C.sizeof(_ffi.DevLane) == 296
+    assert C.sizeof(_ffi.Tuning) == 32
 
 
 def test_version_and_strerror():

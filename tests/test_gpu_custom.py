@@ -1,0 +1,184 @@
+"""Per-lane coefficient sets (VS_VOWEL_CUSTOM), the error path of the wave-specialised kernel,
+and the regression cases of the round-1 review.
+
+The reference's filter loop (vowel_new.c:266-289) runs over whatever A[] coefficients() loaded;
+the engine keeps the 22 coefficients of every lane in that lane's registers, so a batch may carry
+one coefficient set per utterance.  Bit-exact against the CPU oracle in VS_ARITH_EXACT, within
++-1 LSB in VS_ARITH_FMA, on both fused kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import voice_synth_amd as vs
+from voice_synth_amd import _ffi, configs
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = {"single": vs.VS_KERNEL_SINGLE, "ws": vs.VS_KERNEL_WS}
+
+
+def _custom_lanes(n):
+    """n lanes: distinct stable A[] (blended pole sets), per-lane gain (from config 5) and a
+    per-lane pre-emphasis"""
+    lanes, fs, dur, _ = configs.config5_blended_lanes(n)
+    for l in range(n):
+        lanes[l].pre_emphasis = [1.0, 0.0, 0.37, 0.9][l % 4]
+    return lanes, vs.num_samples(fs, dur)
+
+
+@pytest.mark.parametrize("kernel", ["single", "ws"])
+def test_custom_coefficient_sets_per_lane(kernel):
+    lanes, ns = _custom_lanes(100)
+    assert len({tuple(lanes[l].A[:]) for l in range(100)}) > 60       # really per lane
+    want = po.synth(lanes, ns)
+    eng = vs.Engine(0)
+    eng.set_tuning(kernel=KERNELS[kernel])
+    try:
+        got = eng.synth(lanes, ns)
+        assert np.array_equal(got, want), "lanes %s differ" % np.flatnonzero((got != want).any(axis=1))[:10]
+        eng.set_arith(vs.VS_ARITH_FMA)
+        got = eng.synth(lanes, ns)
+        assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+    finally:
+        eng.close()
+
+
+def test_custom_set_equal_to_a_table_equals_the_table(engine):
+    """A[] copied from table '4' must give what -v 4 gives (ties the custom path to the path the
+    reference's golden vectors pin)"""
+    lanes, ns = _custom_lanes(64)
+    ref = (vs.Lane * 64)()
+    C.memmove(ref, lanes, C.sizeof(ref))
+    A = vs.vowel_coefficients("4")
+    for l in range(64):
+        for j in range(23):
+            lanes[l].A[j] = float(A[j])
+        ref[l].vowel = ord("4")
+    assert np.array_equal(engine.synth(lanes, ns), engine.synth(ref, ns))
+
+
+def test_lower_order_sets_by_zero_padding(engine):
+    """orders below 22: trailing coefficients 0.0 (acc - 0*y == acc exactly), e.g. one resonator"""
+    lanes, ns = _custom_lanes(64)
+    for l in range(64):
+        r, th = 0.90 + 0.001 * l, 0.1 + 0.02 * l
+        for j in range(23):
+            lanes[l].A[j] = 0.0
+        lanes[l].A[0], lanes[l].A[1], lanes[l].A[2] = 1.0, -2.0 * r * np.cos(th), r * r
+        lanes[l].gain = 1.0
+    got = engine.synth(lanes, 4000)
+    assert np.array_equal(got, po.synth(lanes, 4000))
+
+
+def test_config5_blended_pole_sets_full_batch_sampled(engine):
+    """BASELINE config 5, first reading of "randomised formant sets" (SURVEY.md 8d): 65536
+    utterances, F0 sweep, each with its own blended pole set; sampled rows against the oracle"""
+    lanes, fs, dur, _ = configs.config5_blended_lanes(65536)
+    ns = vs.num_samples(fs, dur)
+    pcm = engine.synth(lanes, ns)
+    pick = list(range(0, 65536, 409))
+    assert np.array_equal(pcm[pick], po.synth([lanes[i] for i in pick], ns))
+
+
+def test_config2_at_its_real_batch(engine):
+    """BASELINE config 2 at its own size: 1024 utterances = 16 groups, the wave-specialised kernel"""
+    specs, fs, dur, _ = configs.config_specs(2, 1024)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    got = engine.synth(lanes, ns)
+    assert np.array_equal(got, po.synth(lanes, ns))
+    flow = engine.source(lanes, ns)
+    assert np.array_equal(flow, po.source(lanes, ns))
+
+
+def test_ws_kernel_bounded_wait_reaches_the_caller():
+    """vs_tuning.fault withholds the generator wave's progress words: the filter wave's bounded
+    wait must run out, set the launch's error word and vs_synth must return VS_ERR_INTERNAL
+    instead of hanging or returning garbage"""
+    specs, fs, dur, _ = configs.config_specs(3, 200)
+    lanes, d = vs.lanes_from_specs(specs)
+    eng = vs.Engine(0)
+    try:
+        eng.set_tuning(kernel=vs.VS_KERNEL_WS, fault=vs.VS_FAULT_WITHHOLD_PROGRESS, spin_limit=2000)
+        with pytest.raises(vs.VsError) as e:
+            eng.synth(lanes, 4000)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        # ... and the plan-level query reports the raw bits: bit 1 = the filter wave gave up
+        plan = eng.plan(lanes, 4000)
+        out = eng.dev_alloc(200 * 4000 * 2)
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        with pytest.raises(vs.VsError):
+            plan.status()
+        eng.dev_free(out)
+        plan.close()
+        # the same context recovers once the fault is cleared
+        eng.set_tuning()
+        got = eng.synth(lanes, 4000)
+        assert np.array_equal(got, po.synth(lanes, 4000))
+    finally:
+        eng.close()
+
+
+def test_tuning_is_validated(engine):
+    lib = vs.load()
+    for bad in (dict(kernel=7), dict(ready_min=65), dict(ws_pairs=3), dict(gen_low=5), dict(gen_min=-1),
+                dict(fault=9), dict(ring_slots=-24)):
+        t = vs.Tuning()
+        for k, v in bad.items():
+            setattr(t, k, v)
+        assert lib.vs_ctx_set_tuning(engine._ctx, C.byref(t)) == _ffi.VS_ERR_ARG, bad
+    assert lib.vs_ctx_set_tuning(engine._ctx, None) == 0
+
+
+def test_long_period_on_a_half_filled_chip(engine):
+    """review finding: 16385..32768 lanes select two generator/filter pairs per workgroup; with a
+    long period (44.1 kHz, F0 60, jitter) two pairs do not fit the 160 KiB of LDS and the launch
+    failed.  The plan now falls back to one pair (or to the one-wave kernel)."""
+    fa = ["-r", "44100", "-d", "0.5", "-f", "60", "-g", "62", "-j", "3", "-s", "5", "-n", "20"]
+    n = 16448
+    lane, dur = vs.lane_from_cli(fa, ["-v", "a", "-g", "2"], 0)
+    lanes = (vs.Lane * n)()
+    for l in range(n):
+        C.memmove(C.byref(lanes[l]), C.byref(lane), C.sizeof(vs.Lane))
+        lanes[l].seed = 900 + l
+        lanes[l].out_seed = 900 + l
+    ns = 3000
+    got = engine.synth(lanes, ns)
+    pick = list(range(0, n, 257)) + [n - 1]
+    assert np.array_equal(got[pick], po.synth([lanes[i] for i in pick], ns))
+
+
+def test_output_noise_only_on_the_high_rate_lanes(engine):
+    """review finding: the frame-power rows were sized from the lanes WITH vowel -n only; a lane
+    without -n and a lower rate has more frames and overran its row into its neighbour's"""
+    lanes = []
+    for l in range(70):
+        if l % 2 == 0:
+            lane, dur = vs.lane_from_cli(["-r", "16000", "-d", "2", "-j", "1"], ["-v", "a", "-g", "2"], 40 + l)
+        else:
+            lane, dur = vs.lane_from_cli(["-r", "32000", "-d", "1", "-j", "1"], ["-v", "a", "-g", "2", "-n", "20"], 40 + l)
+        lanes.append(lane)
+    ns = 32000
+    got = engine.synth(lanes, ns)
+    want = po.synth(lanes, ns)
+    assert np.array_equal(got, want), np.flatnonzero((got != want).any(axis=1))[:10]
+
+
+def test_filter_only_accepts_any_sample_rate(engine):
+    """review finding: vs_filter validated the SOURCE fields, so a 192 kHz flow (P = fs/F0 beyond
+    the ring) was refused although the filter-only kind has no ring; the reference filters any rate"""
+    lanes = []
+    for l in range(64):
+        lane = vs.default_lane()
+        lane.fs = 192000
+        lane.vowel = ord("aiu1234567"[l % 10])
+        lane.gain = 1.0 + l % 5
+        lane.out_snr = 100.0 if l % 3 == 0 else 0.0
+        lane.out_seed = 77 + l
+        lanes.append(lane)
+    rng = np.random.default_rng(11)
+    flow = rng.integers(-12000, 12000, size=(64, 20000), dtype=np.int16)
+    got = engine.filter(lanes, flow)
+    assert np.array_equal(got, po.filter(lanes, flow))

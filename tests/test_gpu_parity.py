@@ -79,13 +79,17 @@ def test_cycle_log_matches_oracle(engine):
             assert np.array_equal(recs[l][:n][name], r[name]), name
 
 
+KERNELS = {"single": vs.VS_KERNEL_SINGLE, "ws": vs.VS_KERNEL_WS}
+
+
 @pytest.mark.parametrize("kernel", ["single", "ws"])
-def test_both_fused_kernels_bit_exact(monkeypatch, kernel):
+def test_both_fused_kernels_bit_exact(kernel):
     """The plan picks the one-wave kernel for full grids and the wave-specialised kernel
     (generator wave + filter wave per 64 utterances, LDS progress words) for grids that leave
-    half of the SIMDs empty; VS_KERNEL forces either.  Both must be bit-exact on every shape."""
-    monkeypatch.setenv("VS_KERNEL", kernel)
+    half of the SIMDs empty; vs_ctx_set_tuning() forces either.  Both must be bit-exact on
+    every shape."""
     eng = vs.Engine(0)
+    eng.set_tuning(kernel=KERNELS[kernel])
     try:
         for index, n in ((2, 96), (3, 200), (5, 130), (4, 70), (1, 1)):
             lanes, ns = _lanes(index, n)
@@ -102,12 +106,11 @@ def test_both_fused_kernels_bit_exact(monkeypatch, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["single", "ws"])
-def test_noise_below_t4_is_never_consumed_early(monkeypatch, kernel):
+def test_noise_below_t4_is_never_consumed_early(kernel):
     """-l gives a DC flow > 0, so the noise also covers [0, T4) of every cycle and is added to
     samples that were written earlier in the same cycle.  The wave-specialised kernel publishes
     its progress inside a cycle; it must not hand those samples to the filter wave before the
     noise is in (a race that showed as a rare mismatch before it was fenced off)."""
-    monkeypatch.setenv("VS_KERNEL", kernel)
     fa = ["-r", "16000", "-d", "0.5", "-j", "3", "-s", "10", "-n", "5", "-z", "0.5", "-l", "0.1"]
     lanes = []
     for seed in range(700):
@@ -115,6 +118,7 @@ def test_noise_below_t4_is_never_consumed_early(monkeypatch, kernel):
         lanes.append(lane)
     ns = vs.num_samples(16000, dur)
     eng = vs.Engine(0)
+    eng.set_tuning(kernel=KERNELS[kernel])
     try:
         for _ in range(3):
             got = eng.synth(lanes, ns)
@@ -127,7 +131,7 @@ def test_device_selftest(engine):
     """exhaustive on the device: the 3-instruction division shortcut equals IEEE division for
     all 2^31 draws; Philox known answer; integer square root; round2int against the literal form"""
     rc, fails = engine.selftest()
-    assert rc == 0 and fails == [0, 0, 0, 0], fails
+    assert rc == 0 and fails == [0, 0, 0, 0, 0, 0], fails
 
 
 @pytest.mark.parametrize("index,n", [(2, 64), (3, 130), (4, 40), (5, 100)])

@@ -165,7 +165,10 @@ def test_expand_lane_matches_reference_expressions():
     assert d.P == 133 and d.T2 == 37 and d.row == 5       # (int)(16000/120), ceil(.5*.55*133)
     assert F(d.t_hi) == F(1.2) * F(133) and F(d.t_lo) == F(0.8) * F(133)
     assert F(d.a_hi) == F(1.8) * F(12000) and F(d.a_lo) == F(0.2) * F(12000)
-    assert d.tbound == 159 and d.dcs == 0 and d.flags == 7
+    # jitter | shimmer | noise | VS_DF_FAST: amplitude <= 1.8*12000 fits a short, (2*0.65-1)*21600 too,
+    # and the open phase (2*37 samples) ends 8 samples before the shortest period ceil(0.8*133) = 107
+    assert d.tbound == 159 and d.dcs == 0 and d.flags == 7 | _ffi.VS_DF_FAST
+    assert d.thr == 1                                       # ceil(0.25): x < 0.25  <=>  x < 1
     assert (d.key0, d.key1) == (7, 0)
     assert list(d.a) == list(vs.vowel_coefficients("2")[1:])
     row = (C.c_double * d.T2)()
@@ -173,9 +176,25 @@ def test_expand_lane_matches_reference_expressions():
     assert list(row) == [math.cos(4.0 * math.atan(1.0) * k / d.T2) for k in range(d.T2)]
 
 
+def test_fast_flag_bounds():
+    """VS_DF_FAST is set only where the short generator sequences are proved equal to the general
+    ones: samples fit a short before the cast, T2 >= 4, open phase ends 8 samples before min T"""
+    def flags(fa):
+        lane, _ = vs.lane_from_cli(fa, ["-v", "a"], 1)
+        d = _ffi.DevLane()
+        assert vs.load().vs_expand_lane(C.byref(lane), 0, C.byref(d)) == 0
+        return d.flags
+    assert flags(["-r", "16000"]) & _ffi.VS_DF_FAST                              # amp 12000, no shimmer
+    assert flags(["-r", "16000", "-a", "20000", "-s", "5"]) & _ffi.VS_DF_FAST == 0   # 1.8*20000 > 32767
+    assert flags(["-r", "16000", "-a", "20000"]) & _ffi.VS_DF_FAST                # without shimmer 20000 fits
+    assert flags(["-r", "16000", "-k", "1.2", "-z", "1", "-a", "30000"]) & _ffi.VS_DF_FAST == 0  # (2*2.4-1)*30000
+    assert flags(["-r", "16000", "-c", "1.0", "-j", "5"]) & _ffi.VS_DF_FAST == 0  # 2*T2 = P+1 > 0.8*P
+    assert flags(["-r", "8000", "-f", "390", "-g", "400", "-c", "0.2"]) & _ffi.VS_DF_FAST == 0  # T2 = 2
+
+
 def test_ring_slots():
     s = C.c_int()
-    assert vs.load().vs_ring_slots_for(159, C.byref(s)) == 0 and s.value >= 24 + 159 and s.value % 24 == 0
+    assert vs.load().vs_ring_slots_for(159, C.byref(s)) == 0 and s.value >= 24 + 159 + 8 and s.value % 24 == 0
     assert vs.load().vs_ring_slots_for(5000, C.byref(s)) == _ffi.VS_ERR_UNSUPPORTED
 
 

@@ -14,6 +14,7 @@ from ._ffi import (  # noqa: F401
     CycleRec,
     FlowgenCmd,
     Lane,
+    Tuning,
     VowelCmd,
     VsError,
     VS_ARITH_EXACT,
@@ -24,6 +25,10 @@ from ._ffi import (  # noqa: F401
     VS_KIND_FILTER,
     VS_KIND_SOURCE,
     VS_KIND_SYNTH,
+    VS_KERNEL_AUTO,
+    VS_KERNEL_SINGLE,
+    VS_KERNEL_WS,
+    VS_FAULT_WITHHOLD_PROGRESS,
     check,
     load,
 )
@@ -161,6 +166,18 @@ class Engine:
         check(self._lib.vs_ctx_set_arith(self._ctx, int(arith)), "vs_ctx_set_arith")
         self.arith = int(arith)
 
+    def set_tuning(self, **kw):
+        """vs_ctx_set_tuning(): keyword arguments are vs_tuning fields (kernel=, ring_slots=,
+        ready_min=, ws_pairs=, gen_low=, gen_min=, spin_limit=, fault=); no arguments resets.
+        Applies to plans made afterwards."""
+        if not kw:
+            check(self._lib.vs_ctx_set_tuning(self._ctx, None), "vs_ctx_set_tuning")
+            return
+        t = Tuning()
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        check(self._lib.vs_ctx_set_tuning(self._ctx, C.byref(t)), "vs_ctx_set_tuning")
+
     def set_stream(self, hip_stream):
         check(self._lib.vs_ctx_set_stream(self._ctx, C.c_void_p(int(hip_stream))), "vs_ctx_set_stream")
 
@@ -168,8 +185,8 @@ class Engine:
         check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
 
     def selftest(self):
-        """(rc, [division shortcut, philox, isqrt, round2int] failure counts)"""
-        f = (C.c_uint64 * 4)()
+        """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2] failure counts)"""
+        f = (C.c_uint64 * 6)()
         rc = self._lib.vs_ctx_selftest(self._ctx, f)
         return rc, [int(v) for v in f]
 

@@ -116,7 +116,31 @@ class DevLane(C.Structure):
         ("Lframe", C.c_int32),
         ("okey0", C.c_uint32),
         ("okey1", C.c_uint32),
+        ("thr", C.c_int32),
+        ("pad_", C.c_int32),
     ]
+
+
+class Tuning(C.Structure):
+    """struct vs_tuning (all zero = the library's own choices)"""
+
+    _fields_ = [
+        ("kernel", C.c_int32),
+        ("ring_slots", C.c_int32),
+        ("ready_min", C.c_int32),
+        ("ws_pairs", C.c_int32),
+        ("gen_low", C.c_int32),
+        ("gen_min", C.c_int32),
+        ("spin_limit", C.c_int32),
+        ("fault", C.c_int32),
+    ]
+
+
+VS_KERNEL_AUTO = 0
+VS_KERNEL_SINGLE = 1
+VS_KERNEL_WS = 2
+VS_FAULT_WITHHOLD_PROGRESS = 1
+VS_DF_FAST = 0x8
 
 
 # every symbol include/voice_synth.h declares: (restype, argtypes)
@@ -141,6 +165,7 @@ SYMBOLS = {
     "vs_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "vs_ctx_set_arith": (C.c_int, [_vp, C.c_int]),
     "vs_ctx_last_hip_error": (C.c_int, [_vp]),
+    "vs_ctx_set_tuning": (C.c_int, [_vp, _P(Tuning)]),
     "vs_ctx_selftest": (C.c_int, [_vp, _P(C.c_uint64)]),
     "vs_ctx_device_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _P(C.c_int)]),
     "vs_plan_create": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _P(_vp)]),

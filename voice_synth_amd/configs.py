@@ -32,6 +32,67 @@ def philox4x32_10(ctr, key):
     return c
 
 
+JPHS_TABLES = "aiu"       # 11 complex pole pairs each
+MNV_TABLES = "1234567"    # 10 complex pole pairs + 2 real poles each
+
+
+def blend_pole_sets(A1, A2, w):
+    """Random-formant-set construction of SURVEY.md section 8d (first reading): a convex blend of
+    the POLE SETS of two of the reference's tables of the same family, pole by pole in order of
+    angle.  Every blended pole lies on the segment between two poles inside the unit circle, so
+    the blend is stable by construction.  Returns the 23 denominator coefficients (A[0] = 1)."""
+    def split(A):
+        r = np.roots(np.asarray(A, dtype=np.float64))
+        up = sorted([z for z in r if z.imag > 1e-9], key=lambda z: np.angle(z))
+        re = sorted([z.real for z in r if abs(z.imag) <= 1e-9])
+        return up, re
+    u1, r1 = split(A1)
+    u2, r2 = split(A2)
+    if len(u1) != len(u2) or len(r1) != len(r2):
+        raise ValueError("pole sets of different structure (blend within one table family)")
+    poles = []
+    for a, b in zip(u1, u2):
+        z = w * a + (1.0 - w) * b
+        poles += [z, np.conj(z)]
+    poles += [w * a + (1.0 - w) * b for a, b in zip(r1, r2)]
+    A = np.real(np.poly(poles))
+    A[0] = 1.0
+    return A
+
+
+def config5_blended_lanes(n_lanes, lane0=0, seed0=1):
+    """BASELINE config 5 with the FIRST reading of "randomised formant sets": per-utterance F0
+    sweep as in config_specs(5, ...) and, per utterance, 23 coefficients of its own -- a convex
+    blend of the pole sets of two tables (VS_VOWEL_CUSTOM) -- plus a per-utterance gain.
+    Returns (Lane array, fs, dur, label).  Parameters from Philox key (0xC0FFEE, lane)."""
+    import ctypes as C
+
+    import voice_synth_amd as vs
+
+    n = int(n_lanes)
+    lanes_idx = np.arange(lane0, lane0 + n, dtype=np.int64)
+    specs, fs, dur, _ = config_specs(5, n, lane0, seed0)
+    arr, d = vs.lanes_from_specs(specs)
+    w = philox4x32_10([np.ones(n), np.zeros(n), np.zeros(n), np.zeros(n)],
+                      [np.full(n, 0xC0FFEE), lanes_idx.astype(np.uint64)])
+    u = [x.astype(np.float64) / 4294967296.0 for x in w]
+    tabs = {t: vs.vowel_coefficients(t) for t in JPHS_TABLES + MNV_TABLES}
+    cache = {}
+    for i in range(n):
+        fam = JPHS_TABLES if u[0][i] < 0.3 else MNV_TABLES
+        t1 = fam[int(u[1][i] * len(fam)) % len(fam)]
+        t2 = fam[int(u[2][i] * len(fam)) % len(fam)]
+        wq = round(float(u[3][i]), 3)           # 1000 blend weights: the root finding is cached
+        key = (t1, t2, wq)
+        if key not in cache:
+            cache[key] = blend_pole_sets(tabs[t1], tabs[t2], wq)
+        arr[i].vowel = 0                         # VS_VOWEL_CUSTOM
+        for j in range(23):
+            arr[i].A[j] = float(cache[key][j])
+    label = "config5b: batch %d F0 sweep 80-300 Hz, per-utterance blended pole sets + gain, 16 kHz 1 s" % n
+    return arr, fs, d, label
+
+
 def config_specs(index, n_lanes=None, lane0=0, seed0=1):
     """Returns (specs, fs, dur, label).  specs[i] = (flowgen_args, vowel_args, seed) of lane
     lane0+i.  n_lanes defaults to the configuration's full batch."""

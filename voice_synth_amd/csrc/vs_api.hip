@@ -29,7 +29,7 @@
 
 extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
 extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1,
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream);
 
@@ -42,6 +42,7 @@ struct vs_ctx {
   int last_hip_error;
   char name[128];
   int cu_count;
+  vs_tuning tuning; /* all zero = the library's own choices */
 };
 
 struct vs_plan {
@@ -59,6 +60,11 @@ struct vs_plan {
   float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
   long opow_pitch;
   int wave_specialised;
+  int ws_pairs;      /* generator/filter pairs per workgroup of the wave-specialised launch */
+  int ws_pair_bytes; /* LDS bytes of one pair */
+  int filter_only;   /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
+  int pre1;          /* every lane has pre_emphasis == 1.0 (the reference's default) */
+  vs_tuning tuning;  /* the context's tuning when the plan was made */
 };
 
 #define VS_HIP(ctx, call)                        \
@@ -89,7 +95,50 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   ctx->last_hip_error = 0;
   snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
   ctx->cu_count = prop.multiProcessorCount;
+  memset(&ctx->tuning, 0, sizeof(ctx->tuning));
+  /* Experiments only (tools/gpu_sweep.sh): with VS_DEBUG_TUNING=1 in the environment the knobs
+   * are read ONCE, here, and go through the same validation as vs_ctx_set_tuning().  Without it
+   * no environment variable can change what the library launches. */
+  {
+    const char *dbg = getenv("VS_DEBUG_TUNING");
+    if (dbg && strcmp(dbg, "1") == 0) {
+      vs_tuning t;
+      memset(&t, 0, sizeof(t));
+      const char *v;
+      if ((v = getenv("VS_KERNEL")) != nullptr) t.kernel = strcmp(v, "ws") == 0 ? VS_KERNEL_WS : (strcmp(v, "single") == 0 ? VS_KERNEL_SINGLE : VS_KERNEL_AUTO);
+      if ((v = getenv("VS_RING_SLOTS")) != nullptr) t.ring_slots = atoi(v);
+      if ((v = getenv("VS_READY_MIN")) != nullptr) t.ready_min = atoi(v);
+      if ((v = getenv("VS_WS_PAIRS")) != nullptr) t.ws_pairs = atoi(v);
+      if ((v = getenv("VS_GEN_LOW")) != nullptr) t.gen_low = atoi(v);
+      if ((v = getenv("VS_GEN_MIN")) != nullptr) t.gen_min = atoi(v);
+      if (vs_ctx_set_tuning(ctx, &t) != VS_OK) {
+        delete ctx;
+        return VS_ERR_ARG;
+      }
+    }
+  }
   *out = ctx;
+  return VS_OK;
+}
+
+extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
+{
+  if (!ctx) return VS_ERR_ARG;
+  if (!t) {
+    memset(&ctx->tuning, 0, sizeof(ctx->tuning));
+    return VS_OK;
+  }
+  if (t->kernel != VS_KERNEL_AUTO && t->kernel != VS_KERNEL_SINGLE && t->kernel != VS_KERNEL_WS) return VS_ERR_ARG;
+  if (t->ring_slots < 0 || t->ring_slots > 65536) return VS_ERR_ARG;
+  if (t->ready_min < 0 || t->ready_min > 64) return VS_ERR_ARG;
+  if (t->ws_pairs < 0 || t->ws_pairs > 2) return VS_ERR_ARG;
+  /* a lane short of gen_low samples starts a round at once: below one super-step the filter wave
+   * could starve while the generator waits for company */
+  if (t->gen_low != 0 && t->gen_low < VS_SS) return VS_ERR_ARG;
+  if (t->gen_min < 0 || t->gen_min > 64) return VS_ERR_ARG;
+  if (t->spin_limit < 0) return VS_ERR_ARG;
+  if (t->fault != 0 && t->fault != VS_FAULT_WITHHOLD_PROGRESS) return VS_ERR_ARG;
+  ctx->tuning = *t;
   return VS_OK;
 }
 
@@ -130,7 +179,7 @@ extern "C" int vs_ctx_synchronize(vs_ctx *ctx)
 extern "C" int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
 {
   if (!ctx) return VS_ERR_ARG;
-  unsigned long long *d = nullptr, h[4] = {0, 0, 0, 0};
+  unsigned long long *d = nullptr, h[VS_SELFTEST_COUNTERS] = {0};
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipMalloc((void **)&d, sizeof(h)));
   hipError_t e = hipMemsetAsync(d, 0, sizeof(h), ctx->stream);
@@ -142,9 +191,12 @@ extern "C" int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
     ctx->last_hip_error = (int)e;
     return VS_ERR_HIP;
   }
-  if (failures)
-    for (int k = 0; k < 4; k++) failures[k] = h[k];
-  return (h[0] | h[1] | h[2] | h[3]) ? VS_ERR_INTERNAL : VS_OK;
+  unsigned long long any = 0;
+  for (int k = 0; k < VS_SELFTEST_COUNTERS; k++) {
+    if (failures) failures[k] = h[k];
+    any |= h[k];
+  }
+  return any ? VS_ERR_INTERNAL : VS_OK;
 }
 
 extern "C" int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr)
@@ -211,10 +263,23 @@ extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
   if ((lane->flags & VS_FLAG_JITTER) && lane->jitter != 0.0) f |= VS_DF_JITTER;
   if ((lane->flags & VS_FLAG_SHIMMER) && lane->shimmer != 0.0) f |= VS_DF_SHIMMER;
   if (lane->flags & VS_FLAG_NOISE) f |= VS_DF_NOISE;
-  d->flags = f;
   /* longest admissible period: T is an integer with (float)T <= t_hi */
   d->tbound = (f & VS_DF_JITTER) ? (int)floorf(d->t_hi) : P;
   if (d->tbound < P) d->tbound = P;
+  /* for an integer sample x: (float)x < par.DC  <=>  x < ceil(par.DC)   (fg:320, 329) */
+  d->thr = (lane->DC < 2147483000.0f) ? (int32_t)ceilf(lane->DC) : 2147483647;
+  /* VS_DF_FAST (vs_device.h): bounds under which the generator's short sequences equal the
+   * general ones.  Largest admissible amplitude: (float)1.8*amp with shimmer (fg:306), amp
+   * without; the rising flank reaches ceil(Amplitude), the falling one Amplitude*(1 - 2*Knew)
+   * with Knew <= K*(1 + Kvar) (fg:325). */
+  {
+    const double amax = (f & VS_DF_SHIMMER) ? (double)d->a_hi : (double)lane->amp;
+    const double kmax = (double)lane->K * (1.0 + (double)lane->Kvar) * 1.000001;
+    const int tmin = (f & VS_DF_JITTER) ? (int)ceilf(d->t_lo) : P; /* rejection keeps (float)T >= t_lo */
+    const bool in_short = amax <= 32767.0 && (2.0 * kmax - 1.0) * amax <= 32767.0 && lane->DC <= 32767.0f;
+    if (in_short && d->T2 >= 4 && 2 * d->T2 + VS_TRASH_ROWS <= tmin) f |= VS_DF_FAST;
+  }
+  d->flags = f;
   d->key0 = (uint32_t)lane->seed;
   d->key1 = (uint32_t)(lane->seed >> 32);
   d->row = row;
@@ -249,11 +314,10 @@ extern "C" void vs_cos_row(int T2, double *row)
 extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
 {
   const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
-  const int need = ((VS_SS + tmax + VS_SS - 1) / VS_SS) * VS_SS;
+  /* one super-step + the longest cycle + the slots a trip may run past the cycle */
+  const int need = ((VS_SS + tmax + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
   if (need > hard_limit) return VS_ERR_UNSUPPORTED;
-  if (cap <= 0) cap = 288; /* (288 + 1) rows * 128 B = 36.1 KiB + cos rows + sync words: four workgroups per CU */
-  const char *env = getenv("VS_RING_SLOTS"); /* tuning knob for experiments */
-  if (env && *env) cap = atoi(env);
+  if (cap <= 0) cap = 288; /* (288 + 8) rows * 128 B = 37 KiB + cos rows + sync words: four workgroups per CU */
   cap = (cap / VS_SS) * VS_SS;
   if (cap > hard_limit) cap = hard_limit;
   int want = ((VS_SS + (int)(1.7 * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
@@ -265,10 +329,6 @@ extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
   if (rho >= 1.65) thr = 64;    /* all of them */
   else if (rho >= 1.45) thr = 58;
   else if (rho >= 1.33) thr = 48;
-  env = getenv("VS_READY_MIN");
-  if (env && *env) thr = atoi(env);
-  if (thr < 1) thr = 1;
-  if (thr > 64) thr = 64;
   *slots = c;
   if (ready_min) *ready_min = thr;
   return VS_OK;
@@ -276,12 +336,48 @@ extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
 
 extern "C" int vs_ring_slots_for(int tmax, int *slots) { return vs_ring_policy(tmax, 0, slots, nullptr); }
 
-extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                              vs_plan **out)
+/* filter-only lane record: gain, pre-emphasis, coefficients, row, vowel -n fields; everything
+ * of the source left zero.  Only the fields the reference's vowel reads are validated, so any
+ * sample rate goes (vowel_new.c:196-205 checks the format tag and the bit depth only). */
+static int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
+{
+  if (!(lane->pre_emphasis >= 0.0 && lane->pre_emphasis <= 1.0)) return VS_ERR_RANGE; /* vw:127 */
+  if (!(lane->gain >= 1)) return VS_ERR_RANGE;                                        /* vw:132 */
+  double A[VS_NCOEF];
+  if (lane->vowel == VS_VOWEL_CUSTOM) {
+    for (int j = 0; j < VS_NCOEF; j++)
+      if (!isfinite(lane->A[j])) return VS_ERR_RANGE;
+    if (lane->A[0] != 1.0) return VS_ERR_RANGE;
+    memcpy(A, lane->A, sizeof(A));
+  } else {
+    int rc = vs_vowel_coefficients(lane->vowel, A);
+    if (rc != VS_OK) return (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') ? VS_ERR_UNSUPPORTED : VS_ERR_RANGE;
+  }
+  if (lane->fs <= 0) return VS_ERR_RANGE;
+  memset(d, 0, sizeof(*d));
+  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j];
+  d->gain = (double)lane->gain;
+  d->pre = (double)lane->pre_emphasis;
+  d->row = row;
+  d->out_snr = lane->out_snr;
+  {
+    const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
+    const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
+    d->Lframe = 50 * milisec1; /* vowel_new.c:361-363 */
+  }
+  if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED;
+  d->okey0 = (uint32_t)lane->out_seed;
+  d->okey1 = (uint32_t)(lane->out_seed >> 32);
+  return VS_OK;
+}
+
+static int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                               int filter_only, vs_plan **out)
 {
   if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
   *out = nullptr;
+  const vs_tuning &tune = ctx->tuning;
   std::vector<VsDevLane> dl;
   std::vector<double> costab;
   std::map<int, int> row_of_T2;
@@ -291,11 +387,17 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     return VS_ERR_NOMEM;
   }
   int tmax = 1;
-  int min_lframe = 0; /* shortest frame among the lanes that ask for output noise */
+  int min_lframe = 0; /* shortest frame of the batch, once any lane asks for output noise */
+  bool any_onoise = false;
   for (size_t l = 0; l < n_lanes; l++) {
-    int rc = vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
+    int rc = filter_only ? vs_expand_filter_lane(&lanes[l], (int32_t)l, &dl[l])
+                         : vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
     if (rc != VS_OK) return rc;
-    if (dl[l].out_snr > 0 && (min_lframe == 0 || dl[l].Lframe < min_lframe)) min_lframe = dl[l].Lframe;
+    /* every lane of a launch with output noise accumulates its frame powers, so the rows of the
+     * power table must hold the lane with the MOST frames, whether it asks for noise or not */
+    if (dl[l].out_snr > 0) any_onoise = true;
+    if (dl[l].Lframe > 0 && (min_lframe == 0 || dl[l].Lframe < min_lframe)) min_lframe = dl[l].Lframe;
+    if (filter_only) continue;
     const int T2 = dl[l].T2;
     std::map<int, int>::iterator it = row_of_T2.find(T2);
     if (it == row_of_T2.end()) {
@@ -309,13 +411,17 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     }
     if (dl[l].tbound > tmax) tmax = dl[l].tbound;
   }
+  bool pre1 = true;
+  for (size_t l = 0; l < n_lanes; l++) pre1 = pre1 && (dl[l].pre == 1.0);
+  if (!any_onoise) min_lframe = 0;
+  if (any_onoise && min_lframe <= 0) return VS_ERR_UNSUPPORTED;
   /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its
    * longest lane and the cos rows of a wavefront are staged once per distinct T2, so a batch with
    * an F0 sweep (BASELINE config 5) is sorted by (P, T2, options) before it is cut into groups of
    * 64.  Placement is internal: each lane still writes its own output row (VsDevLane.row), and a
    * lane's result does not depend on its neighbours.  Stable sort, so homogeneous batches keep
    * their order. */
-  {
+  if (!filter_only) {
     bool mixed = false;
     for (size_t l = 1; l < n_lanes && !mixed; l++)
       mixed = dl[l].P != dl[0].P || dl[l].T2 != dl[0].T2 || dl[l].flags != dl[0].flags;
@@ -334,42 +440,59 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
    *    the WAVE-SPECIALISED kernel -- a generator wavefront and a filter wavefront per group, each
    *    with a SIMD of its own (two pairs per 256-thread workgroup when that makes one workgroup
    *    per CU); 1.35-1.45x faster than leaving half of the SIMDs idle. */
+  const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
   const unsigned grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
-  const unsigned simds = 4u * (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+  const unsigned simds = 4u * cus;
   int wave_specialised = (2u * grid <= simds);
-  {
-    const char *k = getenv("VS_KERNEL"); /* A/B knob: "ws" or "single" forces the choice */
-    if (k && strcmp(k, "ws") == 0) wave_specialised = 1;
-    if (k && strcmp(k, "single") == 0) wave_specialised = 0;
-  }
-  unsigned wg_per_cu = (grid + (unsigned)ctx->cu_count - 1) / (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+  if (tune.kernel == VS_KERNEL_WS) wave_specialised = 1;
+  if (tune.kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
+  if (filter_only) wave_specialised = 0;
+  unsigned wg_per_cu = (grid + cus - 1) / cus;
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
   int cap = 0; /* default: four workgroups per CU */
-  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (VS_WAVE * 2)) - 1;
+  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (VS_WAVE * 2)) - VS_TRASH_ROWS;
+  if (tune.ring_slots > 0) cap = tune.ring_slots;
   int slots = 0, ready_min = 32;
-  int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
-  if (rc != VS_OK) return rc;
-  /* measured on 16384 / 32768 utterances (tools/gpu_sweep.sh): with a SIMD per wavefront the
-   * generator has slack, so it should feed the filter eagerly (rounds from 25 % attendance) and
-   * the filter should not wait for stragglers (super-steps from 62 %); ring size is immaterial */
-  if (wave_specialised && !getenv("VS_READY_MIN")) ready_min = 40;
-  /* cos rows staged per wavefront: sum of the distinct T2 among its 64 lanes, worst wavefront */
   int ltab_entries = 0;
-  for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
-    int seen[VS_WAVE], nseen = 0, sum = 0;
-    for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) {
-      bool dup = false;
-      for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
-      if (!dup) {
-        seen[nseen++] = dl[l].T2;
-        sum += dl[l].T2;
+  size_t lds_bytes = 0;
+  int ws_pairs = 1, ws_pair_bytes = 0;
+  if (!filter_only) {
+    int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
+    if (rc != VS_OK) return rc;
+    /* measured on 16384 / 32768 utterances (tools/gpu_sweep.sh): with a SIMD per wavefront the
+     * generator has slack, so it should feed the filter eagerly (rounds from 25 % attendance) and
+     * the filter should not wait for stragglers (super-steps from 62 %); ring size is immaterial */
+    if (wave_specialised) ready_min = 40;
+    if (tune.ready_min > 0) ready_min = tune.ready_min;
+    /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
+     * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
+    for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
+      int seen[VS_WAVE], nseen = 0, sum = 0;
+      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) {
+        bool dup = false;
+        for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
+        if (!dup) {
+          seen[nseen++] = dl[l].T2;
+          sum += (dl[l].T2 + 7) & ~7;
+        }
       }
+      if (sum > ltab_entries) ltab_entries = sum;
     }
-    if (sum > ltab_entries) ltab_entries = sum;
+    /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
+    lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+    if (lds_bytes > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
+    /* wave-specialised launch shape: one pair = ring + cos rows + the two progress arrays; two
+     * pairs per workgroup when that gives one workgroup per CU AND both fit the CU's LDS; when
+     * not even one pair fits next to its progress words, the one-wave kernel runs instead */
+    ws_pair_bytes = (int)((lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
+    if (wave_specialised) {
+      if ((size_t)ws_pair_bytes > VS_LDS_LIMIT) wave_specialised = 0;
+      ws_pairs = (grid > cus && grid <= 2u * cus) ? 2 : 1;
+      if (tune.ws_pairs > 0) ws_pairs = tune.ws_pairs;
+      if (2 * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs = 1;
+    }
   }
-  ltab_entries = (ltab_entries + 1) & ~1;
-  if ((size_t)(slots + 1) * VS_WAVE * 2 + (size_t)ltab_entries * 8 > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
 
   vs_plan *p = new (std::nothrow) vs_plan();
   if (!p) return VS_ERR_NOMEM;
@@ -381,18 +504,22 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   p->ring_slots = slots;
   p->ready_min = ready_min;
   p->ltab_entries = ltab_entries;
-  /* ring rows + one trash row (lanes that must not emit write there) + the cos rows */
-  p->lds_bytes = (size_t)(slots + 1) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+  p->lds_bytes = lds_bytes;
   p->grid = grid;
   p->d_diag = nullptr;
   p->d_err = nullptr;
   p->d_opow = nullptr;
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
+  p->ws_pairs = ws_pairs;
+  p->ws_pair_bytes = ws_pair_bytes;
+  p->filter_only = filter_only;
+  p->pre1 = pre1 ? 1 : 0;
+  p->tuning = tune;
 
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
-  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, costab.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab.size() + 1) * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
@@ -400,7 +527,7 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   if (e == hipSuccess)
     e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
                        ctx->stream);
-  if (e == hipSuccess)
+  if (e == hipSuccess && !costab.empty())
     e = hipMemcpyAsync(p->d_costab, costab.data(), costab.size() * sizeof(double),
                        hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -415,6 +542,12 @@ extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   }
   *out = p;
   return VS_OK;
+}
+
+extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                              vs_plan **out)
+{
+  return vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, 0, out);
 }
 
 extern "C" void vs_plan_destroy(vs_plan *p)
@@ -466,6 +599,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   if (kind != VS_KIND_SYNTH && kind != VS_KIND_SOURCE && kind != VS_KIND_FILTER) return VS_ERR_ARG;
   if (out_pitch < p->n_samples) return VS_ERR_ARG;
   if (kind == VS_KIND_FILTER && (!in_dev || in_pitch < p->n_samples)) return VS_ERR_ARG;
+  if (p->filter_only && kind != VS_KIND_FILTER) return VS_ERR_ARG;
   if (log_dev && log_pitch == 0) return VS_ERR_ARG;
   vs_ctx *ctx = p->ctx;
   VsKernelArgs a;
@@ -488,31 +622,19 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.err = p->d_err;
   a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
   a.opow_pitch = p->opow_pitch;
-  /* wave-specialised launch shape: two pairs per workgroup when that gives one workgroup per CU */
-  {
-    const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
-    a.ws_pairs = (p->grid > cus && p->grid <= 2u * cus) ? 2 : 1;
-    const char *wp = getenv("VS_WS_PAIRS"); /* tuning knob for experiments */
-    if (wp && *wp) a.ws_pairs = (atoi(wp) == 2) ? 2 : 1;
-    a.ws_pair_bytes = (int)((p->lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
-  }
-  a.gen_min = 16;
-  a.gen_low = 2 * VS_SS;
-  {
-    const char *gl = getenv("VS_GEN_LOW"); /* tuning knob for experiments */
-    if (gl && *gl) a.gen_low = atoi(gl);
-  }
-  {
-    const char *gm = getenv("VS_GEN_MIN"); /* tuning knob for experiments */
-    if (gm && *gm) a.gen_min = atoi(gm);
-  }
+  a.ws_pairs = p->ws_pairs;
+  a.ws_pair_bytes = p->ws_pair_bytes;
+  a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : 16;
+  a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : 2 * VS_SS;
+  a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
+  a.fault = p->tuning.fault;
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);
   a.vec_ok = vec;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr,
-                               p->wave_specialised != 0 && a.opow == nullptr, &a, p->grid,
+                               p->wave_specialised != 0 && a.opow == nullptr, p->pre1 != 0, &a, p->grid,
                                p->lds_bytes, ctx->stream));
   if (a.opow) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream)); /* vowel -n, second half */
   return VS_OK;
@@ -527,7 +649,7 @@ static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lan
 {
   if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   vs_plan *plan = nullptr;
-  int rc = vs_plan_create(ctx, lanes, n_lanes, n_samples, &plan);
+  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, kind == VS_KIND_FILTER, &plan);
   if (rc != VS_OK) return rc;
   const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
   const size_t bytes = n_lanes * pitch * sizeof(int16_t);

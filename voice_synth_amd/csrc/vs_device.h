@@ -13,10 +13,20 @@
 #define VS_DF_JITTER 0x1u  /* -j given and non-zero   (flowgen_shimmer.c:248) */
 #define VS_DF_SHIMMER 0x2u /* -s given and non-zero   (flowgen_shimmer.c:295) */
 #define VS_DF_NOISE 0x4u   /* -n given                (flowgen_shimmer.c:373) */
+/* Host-proved bounds that let the generator take its short instruction sequences:
+ *   - every pulse sample fits a signed short before the (signed short) cast, so the cast is the
+ *     identity and both half-pulses are monotone in i (amplitude <= 32767 and
+ *     (2*K*(1+Kvar) - 1) * amplitude <= 32767 for the largest admissible amplitude);
+ *   - the open phase ends at least 8 samples before the shortest admissible period
+ *     (2*T2 + 8 <= min T), so stores that run a few slots past a phase are overwritten by the
+ *     phases behind it. */
+#define VS_DF_FAST 0x8u
 
-/* One utterance as the kernel reads it (288 bytes, 16-byte aligned).  Everything that is a
+#define VS_TRASH_ROWS 8 /* ring rows [C, C+8): where lanes that must not emit send their 8-sample trips */
+
+/* One utterance as the kernel reads it (296 bytes, 8-byte aligned).  Everything that is a
  * pure function of the lane's parameters is evaluated on the host, in C, with the reference's
- * operand types (vs_plan.cpp). */
+ * operand types (vs_expand_lane() in vs_api.hip). */
 typedef struct VsDevLane {
   double a[22];       /* A[1..22]                                      vowel_new.c:279-281 */
   double gain;        /* (double)gain                                  vowel_new.c:268 */
@@ -36,6 +46,8 @@ typedef struct VsDevLane {
   float out_snr;      /* vowel -n: linear SNR of the noise added to the filtered signal, 0 = off */
   int32_t Lframe;     /* 50 * ((int)(fs*0.001/2.0)*2), the frame the noise power is taken over (vowel_new.c:361-363) */
   uint32_t okey0, okey1; /* Philox key of the vowel stage's draw stream */
+  int32_t thr;        /* ceil(par.DC) as an integer: for an integer x, (float)x < par.DC  <=>  x < thr   (fg:320, 329) */
+  int32_t pad_;
 } VsDevLane;
 
 typedef struct VsKernelArgs {
@@ -59,6 +71,8 @@ typedef struct VsKernelArgs {
   long opow_pitch;
   int gen_low;        /* wave-specialised kernel: a lane with fewer buffered samples than this starts a round at once */
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
+  int spin_limit;     /* polls before a waiting wave gives up and sets err */
+  int fault;          /* VS_FAULT_* (tests only) */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;
 

@@ -66,6 +66,12 @@ __device__ __forceinline__ unsigned long long vs_stamp()
 #define VS_DIAG_ADD(dg, k)
 #endif
 
+/* a ^ b ^ c in one instruction (gfx950 V_BITOP3_B32, truth table 0x96) */
+__device__ __forceinline__ uint32_t vs_xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
 /* Philox4x32-10 (Salmon et al., SC'11), counter = (blk, 0, 0, 0). */
 __device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1, uint32_t &o0,
                                           uint32_t &o1, uint32_t &o2, uint32_t &o3)
@@ -75,9 +81,9 @@ __device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)VS_PHILOX_M0 * c0;
     const uint64_t p1 = (uint64_t)VS_PHILOX_M1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n0 = vs_xor3((uint32_t)(p1 >> 32), c1, k0);
     const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n2 = vs_xor3((uint32_t)(p0 >> 32), c3, k1);
     const uint32_t n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += VS_PHILOX_W0;
@@ -86,38 +92,80 @@ __device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1
   o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
 
-/* per-lane constants */
+/* The ten round keys of a lane, made once per glottal cycle for the noise loop (the key
+ * schedule k + r*W does not depend on the counter). */
+struct VsRoundKeys {
+  uint32_t a[10], b[10];
+};
+__device__ __forceinline__ void vs_round_keys(uint32_t k0, uint32_t k1, VsRoundKeys &rk)
+{
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    rk.a[r] = k0 + (uint32_t)r * VS_PHILOX_W0;
+    rk.b[r] = k1 + (uint32_t)r * VS_PHILOX_W1;
+    /* keep them as values: rematerialising the additions inside the loop is what this avoids */
+    asm volatile("" : "+v"(rk.a[r]), "+v"(rk.b[r]));
+  }
+}
+/* two consecutive blocks (blk, blk + 1) with the prepared keys: 8 draws, chains interleaved */
+__device__ __forceinline__ void vs_philox2(uint32_t blk, const VsRoundKeys &rk, uint32_t (&o)[8])
+{
+  uint32_t c0 = blk, c1 = 0u, c2 = 0u, c3 = 0u;
+  uint32_t e0 = blk + 1u, e1 = 0u, e2 = 0u, e3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)VS_PHILOX_M0 * c0;
+    const uint64_t p1 = (uint64_t)VS_PHILOX_M1 * c2;
+    const uint64_t s0 = (uint64_t)VS_PHILOX_M0 * e0;
+    const uint64_t s1 = (uint64_t)VS_PHILOX_M1 * e2;
+    const uint32_t n0 = vs_xor3((uint32_t)(p1 >> 32), c1, rk.a[r]);
+    const uint32_t n2 = vs_xor3((uint32_t)(p0 >> 32), c3, rk.b[r]);
+    const uint32_t m0 = vs_xor3((uint32_t)(s1 >> 32), e1, rk.a[r]);
+    const uint32_t m2 = vs_xor3((uint32_t)(s0 >> 32), e3, rk.b[r]);
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    e1 = (uint32_t)s1; e3 = (uint32_t)s0; e0 = m0; e2 = m2;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+  o[4] = e0; o[5] = e1; o[6] = e2; o[7] = e3;
+}
+
+/* per-lane constants of the generator */
 struct VsCfg {
   float jitter, shimmer, K, Kvar, DC, noise, t_hi, t_lo, a_hi, a_lo;
-  int amp, P, T2, tab_off, dcs;
+  int amp, P, T2, tab_off, dcs, thr;
   uint32_t flags, key0, key1;
 };
 
 /* per-lane generator state: the complete carried state of flowgen_shimmer.c's loop
  * (DeltaPer[0], DeltaShimmer[0], T4, T, CountSamples) plus the draw counter */
 struct VsGen {
-  uint32_t d, blk_idx, b0, b1, b2, b3;
+  uint32_t d;
   float dp0, ds0;
   int T4, T, g, wpos, cyc;
-  /* the next cycle's period / amplitude once its jitter and shimmer draws are made
-   * (vs_cycle_scalars) and before its samples are written (vs_cycle_emit) */
-  float amp_next, S_next;
+  /* the next cycle's period / amplitude / closing speed once its jitter, shimmer and Knew draws
+   * are made (vs_cycle_scalars) and before its samples are written (vs_cycle_emit) */
+  float amp_next, S_next, K_next;
   bool pend;
+};
+
+/* the Philox block the scalar draws of one cycle come from (local to vs_cycle_scalars) */
+struct VsBlk {
+  uint32_t idx, b0, b1, b2, b3;
 };
 
 /* next draw of the lane's sequential stream = what random() returns in the shimmed reference.
  * Called under the EXEC mask of the lanes that draw. */
-__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s)
+__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, VsBlk &k)
 {
   const uint32_t b = s.d >> 2;
-  if (b != s.blk_idx) {
-    vs_philox(b, c.key0, c.key1, s.b0, s.b1, s.b2, s.b3);
-    s.blk_idx = b;
+  if (b != k.idx) {
+    vs_philox(b, c.key0, c.key1, k.b0, k.b1, k.b2, k.b3);
+    k.idx = b;
   }
   /* word (d & 3) of the cached block; written as 64-bit select + shift so that the compiler
    * does not turn a four-way select into an indexed scratch array */
-  const uint64_t q0 = (uint64_t)s.b0 | ((uint64_t)s.b1 << 32);
-  const uint64_t q1 = (uint64_t)s.b2 | ((uint64_t)s.b3 << 32);
+  const uint64_t q0 = (uint64_t)k.b0 | ((uint64_t)k.b1 << 32);
+  const uint64_t q1 = (uint64_t)k.b2 | ((uint64_t)k.b3 << 32);
   const uint64_t q = (s.d & 2u) ? q1 : q0;
   const uint32_t v = (uint32_t)(q >> ((s.d & 1u) * 32u));
   s.d += 1u;
@@ -144,13 +192,16 @@ __device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int
 
 /* round2int() of vowel_new.c:413-427:
  *     dec = x - floor(x); if (dec > 0.5) x = x + 1; clamp x to [-32767, 32767]; return floor(x)
- * The "+1" stays a double addition (it is part of the reference's rounding sequence); the clamp
- * moves behind the floor into integers, which gives the same result for every finite x:
- * floor is monotone, floor(+-32767) = +-32767, and v_cvt_i32_f64 saturates beyond int32.  x is
- * never NaN (stable filter, int16 input). */
+ * dec comes from V_FRACT_F64: x - floor(x) is exact for every double except -1 < x < 0, where both
+ * forms round x + 1 to nearest; the instruction only differs in returning the largest double
+ * below 1 where the subtraction rounds up to 1.0 (tiny negative x), and both are > 0.5 there.
+ * The "+1" stays a double addition (it is part of the reference's rounding sequence: the
+ * reference returns 1 for x = -1e-20); the clamp moves behind the floor into integers, which
+ * gives the same result for every finite x: floor is monotone, floor(+-32767) = +-32767, and
+ * v_cvt_i32_f64 saturates beyond int32.  x is never NaN (stable filter, int16 input). */
 __device__ __forceinline__ int vs_round2int(double x)
 {
-  const double dec = x - floor(x);
+  const double dec = __builtin_amdgcn_fract(x);
   x = x + ((dec > 0.5) ? 1.0 : 0.0); /* x + 0.0 only turns -0.0 into +0.0; both floor to 0 */
   const int v = (int)floor(x);
   return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
@@ -168,32 +219,94 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
 }
 
 /* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
- * at most once, at i == thr (= C - wpos). */
-__device__ __forceinline__ int vs_ring_at(int wpos, int thr, int C, int i, int lane)
+ * at most once (wpos < C, i < C + VS_TRASH_ROWS). */
+__device__ __forceinline__ int vs_ring_at(int wpos, int C, int i, int lane)
 {
   /* slot = (wpos + i) mod C for wpos + i < 2C, as min(s, s - C) on unsigned (two instructions) */
   const unsigned sl = (unsigned)(wpos + i);
   const unsigned wr = sl - (unsigned)C;
-  (void)thr;
   return (int)((sl < wr) ? sl : wr) * VS_WAVE + lane;
+}
+
+/* Eight consecutive ring slots of a lane, starting at cycle sample i0: the run wraps at most once,
+ * after kw slots.  A sample costs one compare, one select and the store (the slot offset w*128
+ * sits in the store's immediate). */
+struct VsRun8 {
+  char *A, *B; /* LDS address of slot i0 before / after the wrap */
+  int kw;      /* slots before the wrap (>= 8: none in this run) */
+};
+__device__ __forceinline__ VsRun8 vs_run8(int16_t *ring, int wpos, int C, int i0, int lane)
+{
+  const unsigned sl = (unsigned)(wpos + i0);
+  const unsigned wr = sl - (unsigned)C;
+  const unsigned a0 = (sl < wr) ? sl : wr;
+  VsRun8 r;
+  r.kw = C - (int)a0;
+  r.A = (char *)ring + (a0 * (unsigned)(VS_WAVE * 2) + (unsigned)(2 * lane));
+  r.B = r.A - (unsigned)C * (unsigned)(VS_WAVE * 2);
+  return r;
+}
+/* all eight stores of a lane go to the trash rows [C, C + 8) */
+__device__ __forceinline__ VsRun8 vs_run8_trash(int16_t *ring, int C, int lane)
+{
+  VsRun8 r;
+  r.kw = 8;
+  r.A = (char *)ring + ((unsigned)C * (unsigned)(VS_WAVE * 2) + (unsigned)(2 * lane));
+  r.B = r.A;
+  return r;
+}
+/* a lane's run if it still emits, the trash rows otherwise (field by field: a select of whole
+ * structs makes the compiler index them in scratch memory) */
+__device__ __forceinline__ VsRun8 vs_run8_or_trash(bool emit, int16_t *ring, int wpos, int C, int i0, int lane)
+{
+  const VsRun8 a = vs_run8(ring, wpos, C, i0, lane);
+  const VsRun8 t = vs_run8_trash(ring, C, lane);
+  VsRun8 r;
+  r.kw = emit ? a.kw : t.kw;
+  r.A = emit ? a.A : t.A;
+  r.B = emit ? a.B : t.B;
+  return r;
+}
+template <int W>
+__device__ __forceinline__ void vs_run8_store(const VsRun8 &r, int v)
+{
+  char *p = (W < r.kw) ? r.A : r.B;
+  *(int16_t *)(p + W * VS_WAVE * 2) = (int16_t)v;
+}
+/* the same, but to the trash rows (address trashA of row C) unless ok */
+template <int W>
+__device__ __forceinline__ void vs_run8_store_if(const VsRun8 &r, char *trashA, bool ok, int v)
+{
+  char *p = (W < r.kw) ? r.A : r.B;
+  p = ok ? p : trashA;
+  *(int16_t *)(p + W * VS_WAVE * 2) = (int16_t)v;
+}
+__device__ __forceinline__ void vs_run8_store_all(const VsRun8 &r, const int (&x)[8])
+{
+  vs_run8_store<0>(r, x[0]); vs_run8_store<1>(r, x[1]); vs_run8_store<2>(r, x[2]); vs_run8_store<3>(r, x[3]);
+  vs_run8_store<4>(r, x[4]); vs_run8_store<5>(r, x[5]); vs_run8_store<6>(r, x[6]); vs_run8_store<7>(r, x[7]);
 }
 
 /*
  * One glottal cycle of a lane is produced in two halves, vs_cycle_scalars() and vs_cycle_emit().
  */
-/* First half of a cycle: the jitter and shimmer recursions with their rejection loops
- * (flowgen_shimmer.c:248-313).  They only consume draws and fix the cycle's period T and
- * amplitude -- no ring space is needed yet, so a lane runs them as soon as its previous cycle
- * is written, and the room check for the samples can use the ACTUAL period instead of the
- * worst case 1.2*P. */
+/* First half of a cycle: every draw of the cycle except the noise -- the jitter and shimmer
+ * recursions with their rejection loops (flowgen_shimmer.c:248-313) and the closing-speed draw
+ * (fg:325; the rising half-pulse between them consumes no draws, so the draw index is the same).
+ * They fix the cycle's period T, amplitude and Knew -- no ring space is needed yet, so a lane
+ * runs them as soon as its previous cycle is written, and the room check for the samples can
+ * use the ACTUAL period instead of the worst case 1.2*P.  The Philox block the draws come from
+ * lives only inside this function. */
 __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDiag &dg)
 {
   VS_DIAG_ADD(dg, 7)
+  VsBlk blk;
+  blk.idx = 0xFFFFFFFFu; blk.b0 = blk.b1 = blk.b2 = blk.b3 = 0u;
   /* ---- jitter: fg:248-291 ---- */
   if (c.flags & VS_DF_JITTER) {
     const float dp1 = s.dp0; /* DeltaPer[1] = DeltaPer[0] */
     for (;;) {
-      const uint32_t r = vs_draw(c, s);
+      const uint32_t r = vs_draw(c, s, blk);
       const float J = (float)(((double)r / (2147483647 * 10000.0)) * 40000.0 * (double)c.jitter -
                               2.0 * (double)c.jitter);
       const double Jd = (double)J;
@@ -209,7 +322,7 @@ __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDia
   if (c.flags & VS_DF_SHIMMER) {
     const float ds1 = s.ds0;
     for (;;) {
-      const uint32_t r = vs_draw(c, s);
+      const uint32_t r = vs_draw(c, s, blk);
       const float epsilon = (float)r / 2147483648.0f; /* (float)RAND_MAX == 2^31 */
       S = (float)((double)epsilon * 4.0 * (double)c.shimmer - 2.0 * (double)c.shimmer);
       const double Sd = (double)S;
@@ -218,22 +331,72 @@ __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDia
       if (!((Amplitude > c.a_hi) || (Amplitude < c.a_lo))) break;
     }
   }
+  /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
+  {
+    const uint32_t r = vs_draw(c, s, blk);
+    s.K_next = (float)((double)c.K * (1.0 + (double)(2.0f * c.Kvar) * (vs_unit_of_draw(r) - 0.5)));
+  }
   s.amp_next = Amplitude;
   s.S_next = S;
   s.pend = true;
   VS_DIAG_ADD(dg, 0)
 }
 
+/* psum + (float)x*(float)x of flowgen_shimmer.c:376 for an integer sample |x| <= 32767: the
+ * square is exact in 32-bit integers and its conversion rounds exactly as the float product. */
+__device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
+
+/* Largest noise width the short noise sequence takes (see vs_noise_fast()). */
+#define VS_NDW_FAST 65534
+
+/*
+ * w[i] = (signed short)ceil(((1.0*random())/RAND_MAX)*NoiseDistWidth - NoiseDistWidth/2.)
+ * (flowgen_shimmer.c:387, 398) for a draw r in [0, 2^31) and a width N <= VS_NDW_FAST, as
+ *     Kn - trunc(fma(r, -N*inv, Kn + N/2)),     Kn = (N >> 1) + 1,  inv = 0x1.00000002p-31
+ * Why this is the reference's value for every r: with M = 2^31 - 1 (a prime) the exact quantity
+ * V = r*N/M - N/2 is an integer only for r = 0 and r = M; for every other r it lies at least
+ * 1/(2M) = 2.3e-10 from an integer.  The reference's three roundings (quotient, product,
+ * difference) and the single rounding here (N*inv is exact for N < 2^21; r*N*inv = r*N/M *
+ * (1 - 2^-62)) each stay within N * 2^-52 < 1.5e-11 of V, so both round to the same side of
+ * every integer; at r = 0 and r = M both are exact (-N/2 and N/2).  Kn - V > 0, so truncation
+ * is the floor, and ceil(V) = Kn - floor(Kn - V).  |w| <= N/2 < 32768: the short cast is the
+ * identity.  Checked exhaustively over r for a set of N, and over all N at the edge draws, by
+ * tests/test_noise_shortcut.py (CPU) and by vs_ctx_selftest() on the device.
+ */
+struct VsNoiseK {
+  double negc, kh;
+  int xbase; /* (short)DC + Kn: the sample is xbase - trunc(...) */
+};
+__device__ __forceinline__ VsNoiseK vs_noise_consts(int NDW, int dcs)
+{
+  VsNoiseK k;
+  const int Kn = (NDW >> 1) + 1;
+  k.negc = -((double)NDW * 0x1.00000002p-31);
+  k.kh = (double)Kn + (double)NDW / 2.0;
+  k.xbase = dcs + Kn;
+  return k;
+}
+__device__ __forceinline__ int vs_noise_w_minus(const VsNoiseK &k, uint32_t r)
+{
+  return (int)__builtin_fma((double)r, k.negc, k.kh); /* = Kn - w */
+}
+
 /*
  * Second half of a cycle, for every lane that is ACTIVE in the EXEC mask (the caller wraps the
  * call in "if (want)"): the samples -- statement-by-statement restatement of
- * flowgen_shimmer.c:317-423 (scalar form: oracle/vs_oracle.c).  Plain SIMT code: loops have
- * per-lane trip counts and the hardware masks lanes that are done; because all lanes walk the
- * same phase of their own cycle together the masks are nearly full.  Within a loop trip the
- * samples are computed stage by stage so that independent dependency chains interleave (one
- * wavefront per SIMD issues a dependent instruction every ~8 ticks, an independent one every
- * ~5: tools/ubench).
- * ltab is this wavefront's copy of the cos rows in LDS, c.tab_off the lane's row in it.
+ * flowgen_shimmer.c:317-423 (scalar form: oracle/vs_oracle.c).
+ *
+ * Two instruction sequences per phase, same results:
+ *   - the general one follows the reference sample by sample (float compare against DC, the
+ *     (signed short) wrap, stores masked by the end of the cycle);
+ *   - the short one runs when every active lane carries VS_DF_FAST (see vs_device.h): eight
+ *     samples per trip, integer compare against ceil(DC), no wrap, and stores that may run up
+ *     to 7 slots past a phase -- those slots belong to a later phase of the same cycle or to the
+ *     next cycle and are written again before the filter may read them (the room check of the
+ *     caller leaves 8 spare slots).  One wavefront per SIMD pays ~5.3 ticks per instruction
+ *     whatever its type, so instructions are what is being saved.
+ * ltab is this wavefront's copy of the cos rows in LDS (rows padded to a multiple of 8 with
+ * 1.0), c.tab_off the lane's row in it.
  */
 template <bool LOG, bool PUB = false>
 __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t *ring, int C,
@@ -250,16 +413,42 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
   const int T2 = c.T2;
   const int room = N - s.g; /* samples of this cycle that still belong to the utterance */
   const int lim = (T < room) ? T : room; /* samples of this cycle that are emitted */
-  const int wthr = C - s.wpos;
   const double Ad = (double)Amplitude;
   const double Ah = Ad * 0.5; /* "Amplitude * 0.5 * (...)" evaluates (Amplitude*0.5) first */
   const float dcsf = (float)c.dcs;
   const double *trow = ltab + c.tab_off;
   float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
   int T4 = s.T4;
+  /* the short sequences: every active lane proved in range on the host, no per-cycle log */
+  const bool fast = !LOG && __all((c.flags & VS_DF_FAST) != 0);
 
   /* ---- rising half-pulse: fg:318-324 ---- */
-  {
+  if (fast) {
+    const float dcs2 = dcsf * dcsf;
+    for (int i = 0; __any(i < T2); i += 8) {
+      if (i < T2) {
+        int x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ah * (1.0 - trow[i + k])); /* pad: cos = 1 -> 0 */
+        const VsRun8 run = vs_run8(ring, s.wpos, C, i, lane);
+        /* monotone flank: if the trip's first sample is not below DC none of it is */
+        if (__any(x[0] < c.thr)) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const bool lt = (x[k] < c.thr) && (i + k < T2); /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
+            x[k] = lt ? c.dcs : x[k];
+            T4 = lt ? (i + k) : T4;
+            const float acc = psum + vs_sq_f(x[k]);
+            psum = lt ? dcs2 : acc;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
+        }
+        vs_run8_store_all(run, x);
+      }
+    }
+  } else {
     const int nE = (T2 < lim) ? T2 : lim; /* rising samples that are emitted */
     int i = 0;
     for (; i + 4 <= nE; i += 4) {
@@ -285,7 +474,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         const float xf = lt ? dcsf : xf0[k];
         T4 = lt ? (i + k) : T4;
         psum = (lt ? 0.0f : psum) + xf * xf;
-        ring[vs_ring_at(s.wpos, wthr, C, i + k, lane)] = (int16_t)xs;
+        ring[vs_ring_at(s.wpos, C, i + k, lane)] = (int16_t)xs;
       }
     }
     for (; i < T2; ++i) { /* remainder, and (last cycle of the utterance) samples past the end */
@@ -296,25 +485,49 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
       const float xf = lt ? dcsf : xf0;
       T4 = lt ? i : T4;
       psum = (lt ? 0.0f : psum) + xf * xf;
-      if (i < lim) ring[vs_ring_at(s.wpos, wthr, C, i, lane)] = (int16_t)xs;
+      if (i < lim) ring[vs_ring_at(s.wpos, C, i, lane)] = (int16_t)xs;
     }
   }
   s.T4 = T4;
 
   VS_DIAG_ADD(dg, 1)
-  /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
-  float Knew;
-  {
-    const uint32_t r = vs_draw(c, s);
-    Knew = (float)((double)c.K * (1.0 + (double)(2.0f * c.Kvar) * (vs_unit_of_draw(r) - 0.5)));
-  }
-  const double Kd = (double)Knew;
+  /* ---- closing speed: fg:325, drawn in vs_cycle_scalars ---- */
+  const double Kd = (double)s.K_next;
 
   /* ---- falling half-pulse: fg:327-332 ---- */
   int T3 = 2 * T2;
   {
     bool run = true;
-    for (int k0 = 0; run && (k0 < T2); k0 += 4) {
+    int kdone = 0; /* falling samples this lane has been through (lanes of a wave may differ in T2) */
+    if (fast) {
+      /* whole trips of 8 (k0 + 8 <= T2); the flank falls monotonically, so a trip whose last
+       * sample is not below DC holds no break.  Stores are unconditional: slots at and behind
+       * the break are written again by the closed phase (2*T2 + 8 <= T). */
+      for (int k0 = 0; __any(run && (k0 + 8 <= T2)); k0 += 8) {
+        if (run && (k0 + 8 <= T2)) {
+          kdone = k0 + 8;
+          int x[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ad * ((Kd * trow[k0 + k] - Kd) + 1.0));
+          const VsRun8 r8 = vs_run8(ring, s.wpos, C, T2 + k0, lane);
+          if (__any(x[7] < c.thr)) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const bool brk = run && (x[k] < c.thr); /* if(x[i] < par.DC) break; */
+              T3 = brk ? (T2 + k0 + k) : T3;
+              run = run && !brk;
+              psum = run ? (psum + vs_sq_f(x[k])) : psum;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
+          }
+          vs_run8_store_all(r8, x);
+        }
+      }
+    }
+    /* general sequence: everything when !fast, the last T2 mod 8 samples otherwise */
+    for (int k0 = kdone; run && (k0 < T2); k0 += 4) {
       double v[4];
       int xsv[4];
       float xfv[4];
@@ -343,7 +556,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         run = run && !brk;
         const bool keep = act && !brk;
         psum = keep ? (psum + xfv[k] * xfv[k]) : psum;
-        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, wthr, C, i, lane) : (C * VS_WAVE + lane)] =
+        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, C, i, lane) : (C * VS_WAVE + lane)] =
             (int16_t)xsv[k];
       }
     }
@@ -363,7 +576,16 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
 
   if (!noisy) {
     /* ---- closed phase without noise: fg:334-336 ---- */
-    for (int i = T3; i < lim; ++i) ring[vs_ring_at(s.wpos, wthr, C, i, lane)] = (int16_t)c.dcs;
+    if (fast) {
+      /* trips of 8 from T3; the last one may run up to 7 slots into the next cycle */
+      for (int i = T3; __any(i < T); i += 8) {
+        const VsRun8 r8 = vs_run8_or_trash(i < T, ring, s.wpos, C, i, lane);
+        const int x[8] = {c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs};
+        vs_run8_store_all(r8, x);
+      }
+    } else {
+      for (int i = T3; i < lim; ++i) ring[vs_ring_at(s.wpos, C, i, lane)] = (int16_t)c.dcs;
+    }
     VS_DIAG_ADD(dg, 3)
   } else {
     /* ---- closed phase with noise: fg:373-411 ---- */
@@ -379,8 +601,64 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
     const uint32_t bfirst = d0 >> 2;
     const int nblk = (m > 0) ? (int)(((d0 + (uint32_t)m - 1u) >> 2) - bfirst) + 1 : 0;
     float wsum = 0.0f;
-    if (T4 == 0) {
-      /* usual case (DC flow 0.25 after -n: T4 == 0): the draws map to i = T3 + q, q = 0..m-1 */
+    /* short sequence: noise only behind the pulse (T4 == 0, the usual case: DC flow 0.25 after
+     * -n), a width the one-fma form is proved for, and samples that cannot reach the clamp */
+    const int absdc = (c.dcs < 0) ? -c.dcs : c.dcs;
+    const bool nfast = fast && __all((T4 == 0) && (NDW <= VS_NDW_FAST) && ((NDW >> 1) + 2 + absdc <= 32767));
+    if (nfast) {
+      /* draw ordinal q = 0..m-1 belongs to sample T3 + q.  Two Philox blocks (8 draws) per
+       * trip; word 0 of the first block has ordinal q0 in -3..0 (the scalar draws of this cycle
+       * sit in front of it), so the first trip masks its leading words.  A lane that is done
+       * (q0 >= m) sends its trips to the trash rows; the trip in which a lane ends may run up to
+       * 7 slots into the next cycle. */
+      VsRoundKeys rk;
+      vs_round_keys(c.key0, c.key1, rk);
+      const VsNoiseK nk = vs_noise_consts(NDW, c.dcs);
+      int q0 = (int)(4u * bfirst - d0);
+      uint32_t b = bfirst;
+      {
+        uint32_t o[8];
+        vs_philox2(b, rk, o);
+        int xv[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) xv[w] = nk.xbase - vs_noise_w_minus(nk, o[w] >> 1);
+        /* T3 + q0 >= 1: VS_DF_FAST lanes have T2 >= 4.  Words in front of the cycle's first
+         * noise draw (q0 + w < 0) go to the trash rows. */
+        const VsRun8 r8 = vs_run8_or_trash(m > 0, ring, s.wpos, C, T3 + q0, lane);
+        char *trashA = vs_run8_trash(ring, C, lane).A;
+        vs_run8_store_if<0>(r8, trashA, q0 + 0 >= 0, xv[0]);
+        vs_run8_store_if<1>(r8, trashA, q0 + 1 >= 0, xv[1]);
+        vs_run8_store_if<2>(r8, trashA, q0 + 2 >= 0, xv[2]);
+        vs_run8_store<3>(r8, xv[3]); vs_run8_store<4>(r8, xv[4]);
+        vs_run8_store<5>(r8, xv[5]); vs_run8_store<6>(r8, xv[6]);
+        vs_run8_store<7>(r8, xv[7]);
+        q0 += 8;
+        b += 2u;
+        if (PUB) {
+          const int done = (q0 < m) ? q0 : m;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      while (__any(q0 < m)) {
+        uint32_t o[8];
+        vs_philox2(b, rk, o);
+        int xv[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) xv[w] = nk.xbase - vs_noise_w_minus(nk, o[w] >> 1);
+        const VsRun8 r8 = vs_run8_or_trash(q0 < m, ring, s.wpos, C, T3 + q0, lane);
+        vs_run8_store_all(r8, xv);
+        q0 += 8;
+        b += 2u;
+        if (PUB) {
+          const int done = (q0 < m) ? q0 : m;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __hip_atomic_store(gpub_lane, s.g + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    } else if (T4 == 0) {
+      /* T4 == 0 on the general sequence: the draws map to i = T3 + q, q = 0..m-1 */
       int mlim = lim - T3;
       mlim = (mlim < m) ? mlim : m;
       mlim = (mlim > 0) ? mlim : 0;
@@ -393,13 +671,6 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         uint32_t o[8];
         vs_philox(b, c.key0, c.key1, o[0], o[1], o[2], o[3]);
         vs_philox(b + 1u, c.key0, c.key1, o[4], o[5], o[6], o[7]);
-        /* keep the last block this lane really used: the next cycle's first draws come from it */
-        const bool two = bi + 1 < nblk;
-        s.b0 = two ? o[4] : o[0];
-        s.b1 = two ? o[5] : o[1];
-        s.b2 = two ? o[6] : o[2];
-        s.b3 = two ? o[7] : o[3];
-        s.blk_idx = two ? (b + 1u) : b;
         double u8[8];
         int wv8[8];
 #pragma unroll
@@ -440,8 +711,6 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         const uint32_t b = bfirst + (uint32_t)bi;
         uint32_t o0, o1, o2, o3;
         vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-        s.b0 = o0; s.b1 = o1; s.b2 = o2; s.b3 = o3;
-        s.blk_idx = b;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
@@ -457,7 +726,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
            * (short) conversion and leaves genuine pulse samples below T4, so those are read
            * back from the ring */
           if (act && (i < lim)) {
-            const int idx = vs_ring_at(s.wpos, wthr, C, i, lane);
+            const int idx = vs_ring_at(s.wpos, C, i, lane);
             const int base = (q < T4) ? (int)ring[idx] : c.dcs;
             int xv = base + wv;
             xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
@@ -499,7 +768,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
  * stores.  y[] is the rotating window of the last 24 outputs in double (y[t] = y at n+t-24
  * on entry, = y at n+t on exit).
  */
-template <int ARITH, int KIND>
+template <int ARITH, int KIND, bool PRE1 = false>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
@@ -549,22 +818,28 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
 #pragma unroll
         for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
       } else {
-        /* four partial sums over the older taps, the newest tap (j = 1) last */
-        double p0 = acc, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        /* two partial sums over the older taps (a lone wavefront issues an independent fp64
+         * instruction every ~5.3 ticks and a dependent one every ~8.4, so two alternating chains
+         * never wait), the newest tap (j = 1) last: it is the only one on the sample-to-sample
+         * critical path */
+        double p0 = acc, p1 = -(a[2] * y[(t + VS_SS - 2) % VS_SS]);
 #pragma unroll
-        for (int j = 2; j <= VS_ORDER; ++j) {
+        for (int j = 3; j <= VS_ORDER; ++j) {
           const double yj = y[(t + VS_SS - j) % VS_SS];
-          if ((j & 3) == 2) p0 = __builtin_fma(-a[j], yj, p0);
-          else if ((j & 3) == 3) p1 = __builtin_fma(-a[j], yj, p1);
-          else if ((j & 3) == 0) p2 = __builtin_fma(-a[j], yj, p2);
-          else p3 = __builtin_fma(-a[j], yj, p3);
+          if (j & 1) p0 = __builtin_fma(-a[j], yj, p0);
+          else p1 = __builtin_fma(-a[j], yj, p1);
         }
-        acc = __builtin_fma(-a[1], y1, (p0 + p1) + (p2 + p3));
+        acc = __builtin_fma(-a[1], y1, p0 + p1);
       }
-      /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284 */
-      const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
+      /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284.  PRE1: every
+       * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
+      const double o = PRE1 ? (acc - y1)
+                            : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
       outv[t] = vs_round2int(o);
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+      /* keep each sample's products next to its chain: hoisted across samples they only park
+       * in the accumulator registers and come back, two moves each way */
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -592,16 +867,19 @@ __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsC
   c.a_hi = L->a_hi; c.a_lo = L->a_lo;
   c.amp = L->amp; c.P = L->P; c.T2 = L->T2; c.tab_off = 0;
   c.dcs = L->dcs;
+  c.thr = L->thr;
   c.flags = L->flags; c.key0 = L->key0; c.key1 = L->key1;
-  s.d = 0u; s.blk_idx = 0xFFFFFFFFu; s.b0 = s.b1 = s.b2 = s.b3 = 0u;
+  s.d = 0u;
   s.dp0 = 0.0f; s.ds0 = 0.0f;
   s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
-  s.amp_next = 0.0f; s.S_next = 0.0f; s.pend = false;
+  s.amp_next = 0.0f; s.S_next = 0.0f; s.K_next = 0.0f; s.pend = false;
 }
 
 /* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its lanes
- * (one pass for a homogeneous batch).  The host sized the region for the worst wavefront of
- * the plan (ltab_entries).  Sets c.tab_off. */
+ * (one pass for a homogeneous batch).  A row occupies T2 rounded up to a multiple of 8, padded
+ * with 1.0: the 8-sample trips of the short rising sequence read past T2 and get
+ * ceil(Ah * (1 - 1)) = 0 there, which adds nothing to the power sum.  The host sized the region
+ * for the worst wavefront of the plan (ltab_entries, same rounding).  Sets c.tab_off. */
 __device__ __forceinline__ void vs_stage_cos_rows(const VsDevLane *__restrict__ L, VsCfg &c,
                                                   double *ltab, const double *__restrict__ costab,
                                                   int ltab_entries, int lane, bool valid)
@@ -614,17 +892,18 @@ __device__ __forceinline__ void vs_stage_cos_rows(const VsDevLane *__restrict__ 
     const int leader = __builtin_ctzll(m);
     const int T2s = __builtin_amdgcn_readlane(c.T2, leader);
     const int gs = __builtin_amdgcn_readlane(gtab, leader);
-    if (used + T2s > ltab_entries) __builtin_trap(); /* plan and kernel disagree */
-    for (int k = lane; k < T2s; k += VS_WAVE) ltab[used + k] = costab[gs + k];
+    const int T2p = (T2s + 7) & ~7;
+    if (used + T2p > ltab_entries) __builtin_trap(); /* plan and kernel disagree */
+    for (int k = lane; k < T2p; k += VS_WAVE) ltab[used + k] = (k < T2s) ? costab[gs + k] : 1.0;
     if (pending && c.T2 == T2s) {
       c.tab_off = used;
       pending = false;
     }
-    used += T2s;
+    used += T2p;
   }
 }
 
-template <int ARITH, int KIND, bool LOG>
+template <int ARITH, int KIND, bool LOG, bool PRE1>
 __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t ring[];
@@ -650,7 +929,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
   VsCfg c;
   VsGen s;
-  double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE); /* row C of the ring is the trash slot */
+  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE); /* rows [C, C+8) are the trash rows */
   if (KIND != VS_KIND_FILTER) {
     vs_load_cfg(L, c, s);
     vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
@@ -683,18 +962,27 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
    * part, and so does a generator round.  Run a super-step when at least ready_min/64 of the
    * live lanes hold 24 samples; otherwise let every lane with room produce its next cycle
    * (the lanes that are short always have room).  Lanes whose periods run long fill their
-   * ring and sit rounds out -- they have fewer cycles to produce anyway. */
+   * ring and sit rounds out -- they have fewer cycles to produce anyway.
+   * A lane's scalar draws for cycle k+1 are made right behind the samples of cycle k, inside the
+   * generator branch: the room check needs the period, and the generator's constants are then
+   * not live across the super-step (which needs every register it can get). */
+  if (KIND != VS_KIND_FILTER) {
+    if (live && (s.g < N)) vs_cycle_scalars(c, s, dg); /* fixes the first period s.T */
+  }
   while (__any(live)) {
     bool ready = live;
     if (KIND != VS_KIND_FILTER) {
       ready = live && ((s.g - n >= VS_SS) || (s.g >= N));
-      if (live && (s.g < N) && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
-      const bool want = live && s.pend && (s.g - n + s.T <= C);
+      /* room for the whole cycle plus the 8 slots a trip of the short sequences may run past it */
+      const bool want = live && s.pend && (s.g - n + s.T + VS_TRASH_ROWS <= C);
       const int n_live = __builtin_popcountll(__ballot(live));
       const int n_ready = __builtin_popcountll(__ballot(ready));
       const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * args.ready_min) || !__any(want));
       if (!filter_now) {
-        if (want) vs_cycle_emit<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
+        if (want) {
+          vs_cycle_emit<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
+          if (s.g < N) vs_cycle_scalars(c, s, dg); /* the next period */
+        }
         continue;
       }
     }
@@ -702,8 +990,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
     /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
     if (ready) {
       int outv[VS_SS];
-      vs_superstep<ARITH, KIND>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
-                                args.vec_ok != 0, outv, xpre);
+      vs_superstep<ARITH, KIND, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
+                                      args.vec_ok != 0, outv, xpre);
       if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
         if (rslot >= C) rslot = 0;
@@ -765,15 +1053,14 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  *
  * Progress: a lane that is short of 24 samples always has room for its next cycle, and wave 0
  * generates whenever such a lane exists; if no lane has room every lane holds more than 24
- * samples and wave 1 runs.  Spins are bounded (VS_SPIN_LIMIT polls, then the error word of
+ * samples and wave 1 runs.  Spins are bounded (args.spin_limit polls, then the error word of
  * the launch is set and the wave leaves) so that a protocol bug cannot hang the device.
  */
-#define VS_SPIN_LIMIT (1 << 22)
 #ifndef VS_POLL_SLEEP
 #define VS_POLL_SLEEP 8 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one */
 #endif
 
-template <int ARITH>
+template <int ARITH, bool PRE1>
 __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
@@ -791,7 +1078,7 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
   const int N = args.n_samples;
   const int C = args.ring_slots;
   int16_t *ring = lds_base + (size_t)pair * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
-  double *ltab = (double *)(ring + (size_t)(C + 1) * VS_WAVE);
+  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE);
   int *gpub = (int *)(ltab + args.ltab_entries);
   int *npub = gpub + VS_WAVE;
   const long row = (long)L->row;
@@ -815,11 +1102,14 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
     int spins = 0;
     for (;;) {
+      /* tests (vs_tuning.fault): a generator that never publishes -- the filter wave's bounded
+       * wait must run out and reach the caller as VS_ERR_INTERNAL */
+      if (args.fault == VS_FAULT_WITHHOLD_PROGRESS) break;
       const bool need = valid && (s.g < N);
       if (!__any(need)) break;
       if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
       const int n_seen = __hip_atomic_load(&npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const bool want = need && (s.g - n_seen + s.T <= C);
+      const bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
       const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
       const int n_need = __builtin_popcountll(__ballot(need));
       const int n_want = __builtin_popcountll(__ballot(want));
@@ -831,7 +1121,7 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
       } else {
         __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
         VS_DIAG_ADD(dg, 6)
-        if (++spins > VS_SPIN_LIMIT) {
+        if (++spins > args.spin_limit) {
           if (args.err && lane == 0) atomicOr(args.err, 1);
           break;
         }
@@ -875,8 +1165,8 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-          vs_superstep<ARITH, VS_KIND_SYNTH>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
-                                             orow, n, N, args.vec_ok != 0, outv, xpre);
+          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
+                                                   orow, n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
@@ -890,7 +1180,7 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
       } else {
         __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
         VS_DIAG_ADD(dg, 6)
-        if (++spins > VS_SPIN_LIMIT) {
+        if (++spins > args.spin_limit) {
           if (args.err && lane == 0) atomicOr(args.err, 2);
           break;
         }
@@ -982,7 +1272,11 @@ extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t 
  *   [2] vs_isqrt_floor(v) == floor(sqrt(v)) for float-valued v on a grid that includes every
  *       perfect square up to 2^24 and its two float neighbours;
  *   [3] vs_round2int(x) against a literal transcription of vowel_new.c:413-427 on a grid around
- *       every half-integer and the clamp edges.
+ *       every half-integer and the clamp edges, tiny negative values and the neighbours of -0.5;
+ *   [4] the one-fma noise sample (vs_noise_w_minus) against the reference's
+ *       (short)ceil((r/RAND_MAX)*N - N/2.) for ALL 2^31 draws at 16 widths N, and for every
+ *       width 0..VS_NDW_FAST at the edge draws;
+ *   [5] vs_philox2 (prepared round keys, two blocks) against vs_philox.
  * bad[k] counts failures of check k.
  */
 __device__ __forceinline__ int vs_round2int_literal(double x)
@@ -994,11 +1288,17 @@ __device__ __forceinline__ int vs_round2int_literal(double x)
   return (int)(int16_t)(int)floor(x);
 }
 
+/* flowgen_shimmer.c:387, 398, literally */
+__device__ __forceinline__ int vs_noise_w_literal(uint32_t r, int N)
+{
+  return (int)(int16_t)(int)ceil(((1.0 * (double)r) / 2147483647.0) * (double)N - (double)N / 2.);
+}
+
 __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *bad)
 {
   const unsigned long long tid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * 256ull;
-  unsigned long long b0 = 0, b2 = 0, b3 = 0;
+  unsigned long long b0 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
   for (unsigned long long r = tid; r < (1ull << 31); r += nthreads) {
     const double ref = (1.0 * (double)(uint32_t)r) / 2147483647.0;
     if (vs_unit_of_draw((uint32_t)r) != ref) b0++;
@@ -1022,9 +1322,49 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     const double x = (double)base + frac;
     if (vs_round2int(x) != vs_round2int_literal(x)) b3++;
   }
+  for (unsigned long long k = tid; k < 4096ull; k += nthreads) {
+    /* -2^-e and -0.5 +- j ulps, e = 1..1074: where x - floor(x) rounds */
+    const int e = (int)(k % 1075ull);
+    const int j = (int)(k / 1075ull);
+    const double tiny = -ldexp(1.0, -e) * (1.0 + 0.25 * (double)j);
+    const double near = __longlong_as_double(__double_as_longlong(-0.5) + (long long)(e % 9) - 4 + 16 * j);
+    if (vs_round2int(tiny) != vs_round2int_literal(tiny)) b3++;
+    if (vs_round2int(near) != vs_round2int_literal(near)) b3++;
+    if (vs_round2int(-tiny) != vs_round2int_literal(-tiny)) b3++;
+  }
+  {
+    const int widths[16] = {1, 2, 3, 7, 100, 2801, 2802, 4095, 4096, 12345, 32767, 32768, 50001, 65532, 65533, VS_NDW_FAST};
+    for (int wi = 0; wi < 16; ++wi) {
+      const int N = widths[wi];
+      const VsNoiseK nk = vs_noise_consts(N, 0);
+      const int Kn = (N >> 1) + 1;
+      for (unsigned long long r = tid; r < (1ull << 31); r += nthreads)
+        if (Kn - vs_noise_w_minus(nk, (uint32_t)r) != vs_noise_w_literal((uint32_t)r, N)) b4++;
+    }
+    const uint32_t edge[12] = {0u, 1u, 2u, 3u, 0x3FFFFFFFu, 0x40000000u, 0x40000001u, 0x7FFFFFFCu, 0x7FFFFFFDu, 0x7FFFFFFEu, 0x7FFFFFFFu, 0x12345678u};
+    for (unsigned long long k = tid; k < (unsigned long long)(VS_NDW_FAST + 1) * 12ull; k += nthreads) {
+      const int N = (int)(k / 12ull);
+      const uint32_t r = edge[k % 12ull];
+      const VsNoiseK nk = vs_noise_consts(N, 0);
+      if (((N >> 1) + 1) - vs_noise_w_minus(nk, r) != vs_noise_w_literal(r, N)) b4++;
+    }
+  }
+  for (unsigned long long k = tid; k < 65536ull; k += nthreads) {
+    const uint32_t blk = (uint32_t)(k * 2654435761ull), k0 = (uint32_t)(k * 40503ull + 1ull), k1 = (uint32_t)(~k * 97ull);
+    VsRoundKeys rk;
+    vs_round_keys(k0, k1, rk);
+    uint32_t o[8], p[8];
+    vs_philox2(blk, rk, o);
+    vs_philox(blk, k0, k1, p[0], p[1], p[2], p[3]);
+    vs_philox(blk + 1u, k0, k1, p[4], p[5], p[6], p[7]);
+    for (int w = 0; w < 8; ++w)
+      if (o[w] != p[w]) b5++;
+  }
   if (b0) atomicAdd(&bad[0], b0);
   if (b2) atomicAdd(&bad[2], b2);
   if (b3) atomicAdd(&bad[3], b3);
+  if (b4) atomicAdd(&bad[4], b4);
+  if (b5) atomicAdd(&bad[5], b5);
   if (tid == 0) {
     unsigned long long b1 = 0;
     uint32_t o0, o1, o2, o3;
@@ -1051,35 +1391,39 @@ extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_
  * ---------------------------------------------------------------------------------------- */
 typedef void (*vs_kernel_fn)(VsKernelArgs);
 
-template <int ARITH, int KIND>
+template <int ARITH, int KIND, bool PRE1>
 static vs_kernel_fn vs_pick_log(bool log)
 {
-  return log ? (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, true>
-             : (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, false>;
+  return log ? (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, true, PRE1>
+             : (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, false, PRE1>;
 }
 
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised,
+/* pre1: every lane has pre_emphasis == 1.0 (the plan knows); only the exact filter has a
+ * shorter sequence for it, the other kinds share one instantiation */
+extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1,
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream)
 {
   vs_kernel_fn fn = nullptr;
   unsigned block = VS_WAVE;
   if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
-    fn = (arith == VS_ARITH_EXACT) ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT>
-                                   : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA>;
+    if (arith == VS_ARITH_EXACT)
+      fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false>;
+    else
+      fn = (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false>;
     /* lds_bytes arrives as the bytes of ONE pair (ring + cos rows + gpub/npub); args->ws_pairs
      * pairs share a workgroup */
     block = 2 * VS_WAVE * (unsigned)args->ws_pairs;
     lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
   } else if (arith == VS_ARITH_EXACT) {
-    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH>(log);
-    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
-    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER>(false);
+    if (kind == VS_KIND_SYNTH) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, true>(log) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, false>(log);
+    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
+    else if (kind == VS_KIND_FILTER) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, true>(false) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, false>(false);
   } else if (arith == VS_ARITH_FMA) {
-    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_SYNTH>(log);
-    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE>(log);
-    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_FILTER>(false);
+    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_SYNTH, false>(log);
+    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
+    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_FILTER, false>(false);
   }
   if (!fn) return hipErrorInvalidValue;
   if (kind == VS_KIND_FILTER) lds_bytes = 0;
