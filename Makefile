@@ -32,11 +32,17 @@ $(CSRC)/vs_host.o: $(CSRC)/vs_host.c $(CSRC)/vs_tables.h include/voice_synth.h
 $(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h include/voice_synth.h
+$(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+$(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(CSRC)/vs_node.o: $(CSRC)/vs_node.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread
 
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
 
@@ -60,5 +66,5 @@ clean:
 diag: $(LIBDIR)/libvoicesynth_diag.so
 $(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
-$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_api.o $(CSRC)/vs_host.o | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm
+$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread

@@ -221,14 +221,44 @@ int vs_ctx_synchronize(vs_ctx *ctx);
  * raw bits).  The one-call conveniences below check it themselves. */
 int vs_plan_status(vs_plan *plan, int *flags);
 
+/* Host cost of vs_plan_create(): host_ms = validation, parameter expansion, sorting, cosine
+ * tables (cut over up to 8 host threads for batches >= 8192); upload_ms = device allocation,
+ * upload and the wait for it.  Neither is part of a launch. */
+int vs_plan_timing(const vs_plan *plan, double *host_ms, double *upload_ms);
+/* Name of the kernel a launch of this kind runs ("vs_synth_kernel<0, 0, false, true>", ...), as
+ * rocprofv3 prints it; for measurement scripts. */
+int vs_plan_kernel_name(const vs_plan *plan, int kind, char *buf, size_t len);
+
 /* Dynamic LDS bytes per 64-lane workgroup and launch geometry a plan will use. */
 int vs_plan_info(const vs_plan *plan, size_t *lds_bytes, size_t *n_workgroups,
                  size_t *ring_slots);
 
-/* ---- one-call conveniences over host buffers (allocate, copy, launch, copy back) ----- */
+/* ---- host-buffer entry points (plan, launch, deliver) --------------------------------- */
 
-/* fg:246-423 then vw:237-331 for every lane; pcm is int16 [n_lanes][n_samples]. */
+/* fg:246-423 then vw:237-331 for every lane; pcm is int16 [n_lanes][n_samples].
+ * The reference writes its samples out cycle by cycle (flowgen_shimmer.c:413-421) and frame by
+ * frame (vowel_new.c:327); here the finished rows cross PCIe in 16 MiB blocks while later
+ * chunks of the batch are still being synthesised (chunks of 16384 utterances, two device
+ * buffers, four DMA workers with pinned staging buffers owned by the context).  If pcm is
+ * PINNED host memory (vs_host_alloc, hipHostMalloc, hipHostRegister) the blocks are DMAed straight
+ * into it; otherwise each block is copied from its staging buffer into pcm by its worker. */
 int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *pcm);
+
+/* The same pipeline with the caller in the place of the memcpy: cb receives `rows` finished
+ * consecutive rows starting at `row0` (int16 [rows][n_samples], contiguous) in a pinned staging
+ * buffer that is valid only during the call.  cb runs on the library's delivery threads, up to
+ * four calls at a time for different blocks, in no particular order; every row is delivered
+ * exactly once.  A non-zero return stops the pipeline with VS_ERR_IO.  (vs_batch writes its
+ * .wav files from here: header + payload, fwrite after fwrite, as the reference does.) */
+typedef int (*vs_rows_cb)(void *user, size_t row0, size_t rows, const int16_t *pcm);
+int vs_synth_rows(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                  vs_rows_cb cb, void *user);
+
+/* Pinned host memory for callers without a HIP binding of their own. */
+int vs_host_alloc(vs_ctx *ctx, size_t bytes, void **ptr);
+int vs_host_free(vs_ctx *ctx, void *ptr);
+/* Releases the buffers the context keeps between calls (device PCM chunks, staging, streams). */
+int vs_ctx_trim(vs_ctx *ctx);
 /* fg:246-423; flow is int16 [n_lanes][n_samples].  recs/ncyc optional (NULL). */
 int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *flow,
               vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc);
@@ -237,6 +267,41 @@ int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_sample
  * any sample rate can be filtered (vowel_new.c:196-205). */
 int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
               const int16_t *flow, int16_t *pcm);
+
+/* ---- one batch over the GPUs of a node --------------------------------------------- */
+
+/* Utterances are independent (all carried state of the reference is per utterance:
+ * flowgen_shimmer.c:121-122, vowel_new.c:90), so a batch shards as contiguous blocks of lanes,
+ * block s = lanes [s*ceil(n/S), (s+1)*ceil(n/S)), with no data-path collective; a lane's draws
+ * are keyed by the seed in its own record, so S shards give byte for byte what one device
+ * gives.  devices[] lists one device per shard; a device may appear more than once ("logical
+ * shards": how the N-device path is exercised on one GPU).  devices[0] is the root.  One
+ * context, two streams and one host thread per shard; calls on a node are not re-entrant. */
+typedef struct vs_node vs_node;
+int vs_node_create(const int *devices, int n_shards, vs_node **node);
+void vs_node_destroy(vs_node *node);
+int vs_node_shards(const vs_node *node);
+int vs_node_ctx(vs_node *node, int shard, vs_ctx **ctx); /* e.g. for vs_ctx_set_tuning */
+int vs_node_set_arith(vs_node *node, int arith);
+int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *lo, size_t *hi);
+/* Synthesis with the final PCM gathered into the ROOT device's memory (root_dev: int16
+ * [n_lanes][root_pitch] on devices[0]).  Every shard works through its block in chunks of 16384
+ * utterances; with VS_NODE_OVERLAP a finished chunk travels to its rows of root_dev by a peer
+ * DMA (one transfer stream per shard = per xGMI link into the root, no ring) while the shard's
+ * next chunk is being synthesised; without it copies and kernels alternate (the comparison
+ * case).  Shards on the root device are synthesised in place unless VS_NODE_STAGE_ALL sends them
+ * through the chunk buffers and the copy too (tests of the transfer path on one GPU).
+ * total_ms: host clock over the whole call; max_compute_ms: the slowest shard from its first
+ * launch to its last kernel's end.  Both optional. */
+#define VS_NODE_OVERLAP 1
+#define VS_NODE_STAGE_ALL 2
+int vs_node_synth_gather(vs_node *node, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         int16_t *root_dev, size_t root_pitch, int flags, double *total_ms,
+                         double *max_compute_ms);
+/* Synthesis with host delivery: every shard runs the vs_synth_rows() pipeline over its own PCIe
+ * link; cb sees global row numbers (and is called from up to 4 threads per shard). */
+int vs_node_synth_rows(vs_node *node, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                       vs_rows_cb cb, void *user);
 
 /* Raw device memory for callers without a HIP binding of their own (the CLIs). */
 int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr);

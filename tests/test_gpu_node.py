@@ -1,0 +1,88 @@
+"""The node-level entry of the C ABI (vs_node_*): contiguous blocks of lanes per shard, finished
+chunks gathered into the root device by peer copies overlapped with the next chunk's kernel.
+With one GPU the shards are LOGICAL (the same device listed N times): the placement logic, the
+chunk pipeline and -- with VS_NODE_STAGE_ALL -- the transfer path all run, and the result must be
+byte for byte what one shard gives ("multi-GPU without 8 GPUs")."""
+import threading
+
+import numpy as np
+import pytest
+
+import voice_synth_amd as vs
+from voice_synth_amd import configs
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def batch(engine):
+    specs, fs, dur, _ = configs.config_specs(3, 50000)   # 8 shards of 6250: ragged groups of 64, chunks of one
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = 2500
+    return lanes, ns, engine.synth(lanes, ns)
+
+
+@pytest.mark.parametrize("shards,flags", [(1, vs.Node.OVERLAP), (8, vs.Node.OVERLAP),
+                                          (8, vs.Node.OVERLAP | vs.Node.STAGE_ALL), (3, vs.Node.STAGE_ALL),
+                                          (2, vs.Node.OVERLAP | vs.Node.STAGE_ALL)])
+def test_gather_into_root_equals_one_device(engine, batch, shards, flags):
+    lanes, ns, want = batch
+    n = len(lanes)
+    pitch = ns + 12                      # a destination pitch of the caller's choosing
+    root = engine.dev_alloc(n * pitch * 2)
+    node = vs.Node([0] * shards)
+    try:
+        tot, comp = node.synth_gather(lanes, ns, root, pitch, flags)
+        got = engine.dev_download(root, (n, pitch))[:, :ns]
+        assert np.array_equal(got, want), (shards, flags)
+        assert tot >= comp > 0
+    finally:
+        node.close()
+        engine.dev_free(root)
+
+
+def test_shard_ranges_are_contiguous_blocks():
+    node = vs.Node([0] * 8)
+    try:
+        edges = [node.shard_range(262144, s) for s in range(8)]
+        assert edges == [(s * 32768, (s + 1) * 32768) for s in range(8)]     # BASELINE config 4
+        edges = [node.shard_range(10, s) for s in range(8)]
+        assert edges[0] == (0, 2) and edges[4] == (8, 10) and edges[5] == (10, 10)
+    finally:
+        node.close()
+
+
+def test_node_rows_to_host_equals_one_device(engine, batch):
+    lanes, ns, want = batch
+    seen = np.zeros(len(lanes), dtype=np.int32)
+    bad = []
+    lock = threading.Lock()
+
+    def fn(row0, rows):
+        ok = np.array_equal(rows, want[row0:row0 + rows.shape[0]])
+        with lock:
+            seen[row0:row0 + rows.shape[0]] += 1
+            if not ok:
+                bad.append(row0)
+        return 0
+
+    node = vs.Node([0] * 4)
+    try:
+        node.synth_rows(lanes, ns, fn)
+    finally:
+        node.close()
+    assert not bad and (seen == 1).all()
+
+
+def test_more_shards_than_lanes(engine):
+    specs, fs, dur, _ = configs.config_specs(3, 5)
+    lanes, d = vs.lanes_from_specs(specs)
+    root = engine.dev_alloc(5 * 2000 * 2)
+    node = vs.Node([0] * 8)
+    try:
+        node.synth_gather(lanes, 2000, root, 2000, vs.Node.OVERLAP | vs.Node.STAGE_ALL)
+        assert np.array_equal(engine.dev_download(root, (5, 2000)), po.synth(lanes, 2000))
+    finally:
+        node.close()
+        engine.dev_free(root)

@@ -36,6 +36,7 @@ from ._ffi import (  # noqa: F401
 __all__ = [
     "Lane",
     "Engine",
+    "Node",
     "Plan",
     "default_lane",
     "parse_flowgen",
@@ -203,6 +204,46 @@ class Engine:
         check(self._lib.vs_synth(self._ctx, arr, len(arr), n_samples, out.ctypes.data), "vs_synth")
         return out
 
+    def synth_pinned(self, lanes, n_samples):
+        """vs_synth() into PINNED host memory from vs_host_alloc(): the finished rows are DMAed
+        straight into the destination.  Returns a numpy view; free it with host_free(view)."""
+        arr = _as_lane_array(lanes)
+        nbytes = len(arr) * n_samples * 2
+        p = C.c_void_p()
+        check(self._lib.vs_host_alloc(self._ctx, nbytes, C.byref(p)), "vs_host_alloc")
+        buf = (C.c_int16 * (len(arr) * n_samples)).from_address(p.value)
+        out = np.frombuffer(buf, dtype=np.int16).reshape(len(arr), n_samples)
+        try:
+            check(self._lib.vs_synth(self._ctx, arr, len(arr), n_samples, p), "vs_synth")
+        except Exception:
+            self._lib.vs_host_free(self._ctx, p)
+            raise
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[out.ctypes.data] = p.value
+        return out
+
+    def host_free(self, view):
+        p = self._pinned.pop(view.ctypes.data)
+        check(self._lib.vs_host_free(self._ctx, C.c_void_p(p)), "vs_host_free")
+
+    def synth_rows(self, lanes, n_samples, fn):
+        """vs_synth_rows(): fn(row0, rows_array) is called for every delivered block (from the
+        library's delivery threads, possibly concurrently); rows_array is only valid inside fn."""
+        arr = _as_lane_array(lanes)
+
+        def tramp(user, row0, rows, ptr):
+            try:
+                buf = (C.c_int16 * (rows * n_samples)).from_address(ptr)
+                return int(fn(int(row0), np.frombuffer(buf, dtype=np.int16).reshape(rows, n_samples)) or 0)
+            except Exception:  # pragma: no cover - surfaces as VS_ERR_IO
+                return 1
+
+        cb = _ffi.ROWS_CB(tramp)
+        check(self._lib.vs_synth_rows(self._ctx, arr, len(arr), n_samples, cb, None), "vs_synth_rows")
+
+    def trim(self):
+        check(self._lib.vs_ctx_trim(self._ctx), "vs_ctx_trim")
+
     def source(self, lanes, n_samples, log_cycles=0):
         arr = _as_lane_array(lanes)
         out = np.empty((len(arr), n_samples), dtype=np.int16)
@@ -253,6 +294,58 @@ class Engine:
               "vs_dev_upload")
 
 
+class Node:
+    """A vs_node: one batch over several devices (or logical shards of one device)."""
+
+    OVERLAP = 1
+    STAGE_ALL = 2
+
+    def __init__(self, devices, arith=VS_ARITH_EXACT):
+        self._lib = load()
+        self._node = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        check(self._lib.vs_node_create(arr, len(devices), C.byref(self._node)), "vs_node_create")
+        check(self._lib.vs_node_set_arith(self._node, int(arith)), "vs_node_set_arith")
+        self.shards = len(devices)
+
+    def close(self):
+        if self._node:
+            self._lib.vs_node_destroy(self._node)
+            self._node = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_range(self, n_lanes, shard):
+        lo, hi = C.c_size_t(), C.c_size_t()
+        check(self._lib.vs_node_shard_range(self._node, n_lanes, shard, C.byref(lo), C.byref(hi)), "vs_node_shard_range")
+        return lo.value, hi.value
+
+    def synth_gather(self, lanes, n_samples, root_ptr, root_pitch, flags=1):
+        """PCM of all shards gathered into device memory of the root; returns (total_ms, max_compute_ms)"""
+        arr = _as_lane_array(lanes)
+        tot, comp = C.c_double(), C.c_double()
+        check(self._lib.vs_node_synth_gather(self._node, arr, len(arr), n_samples, C.c_void_p(root_ptr), root_pitch,
+                                             int(flags), C.byref(tot), C.byref(comp)), "vs_node_synth_gather")
+        return tot.value, comp.value
+
+    def synth_rows(self, lanes, n_samples, fn):
+        arr = _as_lane_array(lanes)
+
+        def tramp(user, row0, rows, ptr):
+            try:
+                buf = (C.c_int16 * (rows * n_samples)).from_address(ptr)
+                return int(fn(int(row0), np.frombuffer(buf, dtype=np.int16).reshape(rows, n_samples)) or 0)
+            except Exception:  # pragma: no cover
+                return 1
+
+        cb = _ffi.ROWS_CB(tramp)
+        check(self._lib.vs_node_synth_rows(self._node, arr, len(arr), n_samples, cb, None), "vs_node_synth_rows")
+
+
 class Plan:
     """A vs_plan: lane records + cos tables resident on the device; launches are asynchronous."""
 
@@ -265,6 +358,17 @@ class Plan:
         self._plan = C.c_void_p()
         check(self._lib.vs_plan_create(engine._ctx, arr, len(arr), n_samples, C.byref(self._plan)),
               "vs_plan_create")
+
+    def timing(self):
+        """(host_ms, upload_ms) of vs_plan_create for this plan"""
+        h, u = C.c_double(), C.c_double()
+        check(self._lib.vs_plan_timing(self._plan, C.byref(h), C.byref(u)), "vs_plan_timing")
+        return h.value, u.value
+
+    def kernel_name(self, kind=VS_KIND_SYNTH):
+        buf = C.create_string_buffer(128)
+        check(self._lib.vs_plan_kernel_name(self._plan, int(kind), buf, 128), "vs_plan_kernel_name")
+        return buf.value.decode()
 
     def info(self):
         lds, wgs, slots = C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -178,6 +178,23 @@ SYMBOLS = {
     "vs_plan_status": (C.c_int, [_vp, _P(C.c_int)]),
     "vs_plan_info": (C.c_int, [_vp, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t)]),
     "vs_synth": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp]),
+    "vs_synth_rows": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, _vp]),
+    "vs_node_create": (C.c_int, [_P(C.c_int), C.c_int, _P(_vp)]),
+    "vs_node_destroy": (None, [_vp]),
+    "vs_node_shards": (C.c_int, [_vp]),
+    "vs_node_ctx": (C.c_int, [_vp, C.c_int, _P(_vp)]),
+    "vs_node_set_arith": (C.c_int, [_vp, C.c_int]),
+    "vs_node_shard_range": (C.c_int, [_vp, C.c_size_t, C.c_int, _P(C.c_size_t), _P(C.c_size_t)]),
+    "vs_node_synth_gather": (
+        C.c_int,
+        [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int, _P(C.c_double), _P(C.c_double)],
+    ),
+    "vs_node_synth_rows": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, _vp]),
+    "vs_host_alloc": (C.c_int, [_vp, C.c_size_t, _P(_vp)]),
+    "vs_host_free": (C.c_int, [_vp, _vp]),
+    "vs_ctx_trim": (C.c_int, [_vp]),
+    "vs_plan_timing": (C.c_int, [_vp, _P(C.c_double), _P(C.c_double)]),
+    "vs_plan_kernel_name": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_size_t]),
     "vs_source": (
         C.c_int,
         [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, _vp, C.c_size_t, _vp],
@@ -218,6 +235,9 @@ def load():
             fn.argtypes = args
     _lib = lib
     return lib
+
+
+ROWS_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p)
 
 
 class VsError(RuntimeError):

@@ -20,8 +20,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/voice_synth.h"
@@ -33,48 +36,7 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream);
 
-#define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
-
-struct vs_ctx {
-  int device;
-  int arith;
-  hipStream_t stream;
-  int last_hip_error;
-  char name[128];
-  int cu_count;
-  vs_tuning tuning; /* all zero = the library's own choices */
-};
-
-struct vs_plan {
-  vs_ctx *ctx;
-  size_t n_lanes, n_samples;
-  VsDevLane *d_lanes;
-  double *d_costab;
-  int ring_slots;
-  int ready_min;
-  int ltab_entries;
-  size_t lds_bytes;
-  unsigned grid;
-  unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
-  int *d_err;                 /* spin-limit word of the wave-specialised kernel */
-  float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
-  long opow_pitch;
-  int wave_specialised;
-  int ws_pairs;      /* generator/filter pairs per workgroup of the wave-specialised launch */
-  int ws_pair_bytes; /* LDS bytes of one pair */
-  int filter_only;   /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
-  int pre1;          /* every lane has pre_emphasis == 1.0 (the reference's default) */
-  vs_tuning tuning;  /* the context's tuning when the plan was made */
-};
-
-#define VS_HIP(ctx, call)                        \
-  do {                                           \
-    hipError_t e_ = (call);                      \
-    if (e_ != hipSuccess) {                      \
-      (ctx)->last_hip_error = (int)e_;           \
-      return VS_ERR_HIP;                         \
-    }                                            \
-  } while (0)
+#include "vs_internal.h"
 
 extern "C" int vs_ctx_create(int device, vs_ctx **out)
 {
@@ -96,6 +58,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
   ctx->cu_count = prop.multiProcessorCount;
   memset(&ctx->tuning, 0, sizeof(ctx->tuning));
+  memset(&ctx->pool, 0, sizeof(ctx->pool));
   /* Experiments only (tools/gpu_sweep.sh): with VS_DEBUG_TUNING=1 in the environment the knobs
    * are read ONCE, here, and go through the same validation as vs_ctx_set_tuning().  Without it
    * no environment variable can change what the library launches. */
@@ -142,7 +105,12 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   return VS_OK;
 }
 
-extern "C" void vs_ctx_destroy(vs_ctx *ctx) { delete ctx; }
+extern "C" void vs_ctx_destroy(vs_ctx *ctx)
+{
+  if (!ctx) return;
+  vs_pool_release(ctx);
+  delete ctx;
+}
 
 extern "C" int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream)
 {
@@ -371,8 +339,8 @@ static int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
   return VS_OK;
 }
 
-static int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                               int filter_only, vs_plan **out)
+int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                        int filter_only, vs_plan **out)
 {
   if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
@@ -386,13 +354,50 @@ static int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes
   } catch (...) {
     return VS_ERR_NOMEM;
   }
+  const auto t_host0 = std::chrono::steady_clock::now();
+  /* expansion of the lane records: independent per lane, so large batches are cut over a few
+   * host threads (65536 lanes: 38 ms on one core, the kernel itself takes 3.5 ms) */
+  {
+    unsigned nt = 1;
+    if (n_lanes >= 8192) {
+      nt = std::thread::hardware_concurrency();
+      if (nt > 8) nt = 8;
+      if (nt < 1) nt = 1;
+    }
+    std::atomic<int> first_rc(VS_OK);
+    auto work = [&](size_t lo, size_t hi) {
+      for (size_t l = lo; l < hi; l++) {
+        const int rc = filter_only ? vs_expand_filter_lane(&lanes[l], (int32_t)l, &dl[l])
+                                   : vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
+        if (rc != VS_OK) {
+          int expect = VS_OK;
+          first_rc.compare_exchange_strong(expect, rc);
+          return;
+        }
+      }
+    };
+    if (nt == 1) {
+      work(0, n_lanes);
+    } else {
+      std::vector<std::thread> th;
+      const size_t per = (n_lanes + nt - 1) / nt;
+      try {
+        for (unsigned t = 0; t < nt; t++) {
+          const size_t lo = (size_t)t * per, hi = std::min(n_lanes, lo + per);
+          if (lo < hi) th.emplace_back(work, lo, hi);
+        }
+      } catch (...) {
+        for (auto &x : th) x.join();
+        return VS_ERR_NOMEM;
+      }
+      for (auto &x : th) x.join();
+    }
+    if (first_rc.load() != VS_OK) return first_rc.load();
+  }
   int tmax = 1;
   int min_lframe = 0; /* shortest frame of the batch, once any lane asks for output noise */
   bool any_onoise = false;
   for (size_t l = 0; l < n_lanes; l++) {
-    int rc = filter_only ? vs_expand_filter_lane(&lanes[l], (int32_t)l, &dl[l])
-                         : vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
-    if (rc != VS_OK) return rc;
     /* every lane of a launch with output noise accumulates its frame powers, so the rows of the
      * power table must hold the lane with the MOST frames, whether it asks for noise or not */
     if (dl[l].out_snr > 0) any_onoise = true;
@@ -517,6 +522,7 @@ static int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes
   p->pre1 = pre1 ? 1 : 0;
   p->tuning = tune;
 
+  const auto t_host1 = std::chrono::steady_clock::now();
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab.size() + 1) * sizeof(double));
@@ -540,6 +546,9 @@ static int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes
     delete p;
     return VS_ERR_HIP;
   }
+  const auto t_host2 = std::chrono::steady_clock::now();
+  p->host_ms = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
+  p->upload_ms = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
   *out = p;
   return VS_OK;
 }
@@ -578,6 +587,27 @@ extern "C" int vs_plan_set_diag(vs_plan *p, void *diag_dev)
 {
   if (!p) return VS_ERR_ARG;
   p->d_diag = (unsigned long long *)diag_dev;
+  return VS_OK;
+}
+
+extern "C" int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_ms)
+{
+  if (!p) return VS_ERR_ARG;
+  if (host_ms) *host_ms = p->host_ms;
+  if (upload_ms) *upload_ms = p->upload_ms;
+  return VS_OK;
+}
+
+extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
+{
+  if (!p || !buf || len == 0) return VS_ERR_ARG;
+  const int ws = p->wave_specialised && kind == VS_KIND_SYNTH && !p->d_opow;
+  const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
+  if (ws)
+    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s>", p->ctx->arith, pre1 ? "true" : "false");
+  else
+    snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
+             pre1 ? "true" : "false");
   return VS_OK;
 }
 
@@ -640,81 +670,3 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   return VS_OK;
 }
 
-/* ------------------------------------------------------------------------------------------
- * One-call conveniences over host buffers
- * ---------------------------------------------------------------------------------------- */
-static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lanes,
-                       size_t n_samples, const int16_t *in_host, int16_t *out_host,
-                       vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
-{
-  if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
-  vs_plan *plan = nullptr;
-  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, kind == VS_KIND_FILTER, &plan);
-  if (rc != VS_OK) return rc;
-  const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
-  const size_t bytes = n_lanes * pitch * sizeof(int16_t);
-  int16_t *d_out = nullptr, *d_in = nullptr;
-  vs_cycle_rec *d_log = nullptr;
-  int32_t *d_ncyc = nullptr;
-  hipError_t e = hipMalloc((void **)&d_out, bytes);
-  if (e == hipSuccess && kind == VS_KIND_FILTER) {
-    e = hipMalloc((void **)&d_in, bytes);
-    if (e == hipSuccess)
-      e = hipMemcpy2DAsync(d_in, pitch * 2, in_host, n_samples * 2, n_samples * 2, n_lanes,
-                           hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (e == hipSuccess && recs && kind != VS_KIND_FILTER) {
-    e = hipMalloc((void **)&d_log, n_lanes * recs_pitch * sizeof(vs_cycle_rec));
-    if (e == hipSuccess)
-      e = hipMemsetAsync(d_log, 0, n_lanes * recs_pitch * sizeof(vs_cycle_rec), ctx->stream);
-  }
-  if (e == hipSuccess && ncyc && kind != VS_KIND_FILTER)
-    e = hipMalloc((void **)&d_ncyc, n_lanes * sizeof(int32_t));
-  if (e == hipSuccess) {
-    rc = vs_plan_launch(plan, kind, d_in, pitch, d_out, pitch, d_log, recs_pitch, d_ncyc);
-    if (rc == VS_OK)
-      e = hipMemcpy2DAsync(out_host, n_samples * 2, d_out, pitch * 2, n_samples * 2, n_lanes,
-                           hipMemcpyDeviceToHost, ctx->stream);
-    if (rc == VS_OK && e == hipSuccess && d_log)
-      e = hipMemcpyAsync(recs, d_log, n_lanes * recs_pitch * sizeof(vs_cycle_rec),
-                         hipMemcpyDeviceToHost, ctx->stream);
-    if (rc == VS_OK && e == hipSuccess && d_ncyc)
-      e = hipMemcpyAsync(ncyc, d_ncyc, n_lanes * sizeof(int32_t), hipMemcpyDeviceToHost,
-                         ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && rc == VS_OK) rc = vs_plan_status(plan, nullptr);
-  }
-  if (d_out) (void)hipFree(d_out);
-  if (d_in) (void)hipFree(d_in);
-  if (d_log) (void)hipFree(d_log);
-  if (d_ncyc) (void)hipFree(d_ncyc);
-  vs_plan_destroy(plan);
-  if (e != hipSuccess) {
-    ctx->last_hip_error = (int)e;
-    return VS_ERR_HIP;
-  }
-  return rc;
-}
-
-extern "C" int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                        int16_t *pcm)
-{
-  return vs_run_host(ctx, VS_KIND_SYNTH, lanes, n_lanes, n_samples, nullptr, pcm, nullptr, 0,
-                     nullptr);
-}
-
-extern "C" int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                         int16_t *flow, vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
-{
-  if (recs && recs_pitch == 0) return VS_ERR_ARG;
-  return vs_run_host(ctx, VS_KIND_SOURCE, lanes, n_lanes, n_samples, nullptr, flow, recs,
-                     recs_pitch, ncyc);
-}
-
-extern "C" int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                         const int16_t *flow, int16_t *pcm)
-{
-  if (!flow) return VS_ERR_ARG;
-  return vs_run_host(ctx, VS_KIND_FILTER, lanes, n_lanes, n_samples, flow, pcm, nullptr, 0,
-                     nullptr);
-}

@@ -1,0 +1,398 @@
+/*
+ * vs_delivery.hip -- the host-buffer entry points of the C ABI: vs_synth_rows() (finished rows
+ * handed to a callback in pinned chunks while later chunks are still being synthesised),
+ * vs_synth() on top of it, vs_source() / vs_filter(), pinned host memory for callers.
+ *
+ * What these replace in the reference is its output path: flowgen_shimmer.c:413-421 and
+ * vowel_new.c:327 fwrite each cycle / frame as it is produced.  Here the PCM of a batch is
+ * produced in HBM and has to cross PCIe (63 GB/s), which takes ~10x longer than synthesising it,
+ * so the crossing is what is organised:
+ *
+ *   compute chunks   the batch is cut into chunks of at most VS_COMPUTE_CHUNK utterances; chunk
+ *                    k+1 is planned on the host and synthesised on the device while chunk k is
+ *                    being delivered (two device buffers, one event each);
+ *   delivery         VS_DELIVERY_THREADS workers, each with its own stream and its own 16 MiB
+ *                    pinned staging buffer, take row blocks of a finished chunk: DMA into the
+ *                    staging buffer, then the callback (vs_synth: one memcpy into the caller's
+ *                    pageable buffer; vs_batch: the .wav files).  Several DMAs and several
+ *                    callbacks are in flight at once; a caller that passes PINNED memory
+ *                    (vs_host_alloc) gets the DMA straight into it, no staging, no memcpy.
+ *
+ * All device and pinned buffers belong to the context and are reused by later calls
+ * (vs_ctx_trim releases them); nothing here calls hipMalloc or hipHostMalloc per call once the
+ * buffers have reached their size, and hipFree (which waits for the device) is never called
+ * while a pipeline runs.
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "vs_internal.h"
+
+#define VS_COMPUTE_CHUNK 16384 /* utterances per compute chunk of the host-buffer pipeline */
+
+/* ------------------------------------------------------------------------------------------
+ * context pool
+ * ---------------------------------------------------------------------------------------- */
+int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes)
+{
+  if (*ptr && *have >= bytes) return VS_OK;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  if (*ptr) {
+    VS_HIP(ctx, hipFree(*ptr)); /* waits for the device: only between pipelines */
+    *ptr = nullptr;
+    *have = 0;
+  }
+  const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  VS_HIP(ctx, hipMalloc(ptr, want));
+  *have = want;
+  return VS_OK;
+}
+
+int vs_pool_streams(vs_ctx *ctx)
+{
+  VsPool &P = ctx->pool;
+  if (P.streams_ready) return VS_OK;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
+    if (!P.copy_stream[t]) VS_HIP(ctx, hipStreamCreateWithFlags(&P.copy_stream[t], hipStreamNonBlocking));
+    if (!P.staging[t]) VS_HIP(ctx, hipHostMalloc(&P.staging[t], VS_STAGING_BYTES, hipHostMallocDefault));
+  }
+  if (!P.compute_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&P.compute_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++)
+    if (!P.done[k]) VS_HIP(ctx, hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
+  P.streams_ready = 1;
+  return VS_OK;
+}
+
+void vs_pool_release(vs_ctx *ctx)
+{
+  VsPool &P = ctx->pool;
+  (void)hipSetDevice(ctx->device);
+  for (int k = 0; k < 2; k++) {
+    if (P.d_out[k]) (void)hipFree(P.d_out[k]);
+    if (P.done[k]) (void)hipEventDestroy(P.done[k]);
+  }
+  if (P.d_in) (void)hipFree(P.d_in);
+  if (P.d_aux) (void)hipFree(P.d_aux);
+  for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
+    if (P.staging[t]) (void)hipHostFree(P.staging[t]);
+    if (P.copy_stream[t]) (void)hipStreamDestroy(P.copy_stream[t]);
+  }
+  if (P.compute_stream) (void)hipStreamDestroy(P.compute_stream);
+  memset(&P, 0, sizeof(P));
+}
+
+extern "C" int vs_ctx_trim(vs_ctx *ctx)
+{
+  if (!ctx) return VS_ERR_ARG;
+  vs_pool_release(ctx);
+  return VS_OK;
+}
+
+extern "C" int vs_host_alloc(vs_ctx *ctx, size_t bytes, void **ptr)
+{
+  if (!ctx || !ptr) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return VS_OK;
+}
+
+extern "C" int vs_host_free(vs_ctx *ctx, void *ptr)
+{
+  if (!ctx) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipHostFree(ptr));
+  return VS_OK;
+}
+
+/* is p pinned host memory the device can DMA into? */
+static bool vs_is_pinned(const void *p)
+{
+  hipPointerAttribute_t at;
+  memset(&at, 0, sizeof(at));
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError(); /* plain malloc memory: not an error for the caller */
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * vs_synth_rows: the pipeline
+ * ---------------------------------------------------------------------------------------- */
+namespace {
+
+struct Block {          /* rows [row0, row0 + rows) of the batch, sitting in device buffer buf */
+  size_t row0, rows;
+  int buf;
+  size_t buf_row0;      /* first row of the chunk that buffer holds */
+};
+
+struct Pipe {
+  vs_ctx *ctx;
+  size_t n_samples, pitch; /* samples per device row */
+  vs_rows_cb cb;
+  void *user;
+  int16_t *direct;         /* pinned destination [n_lanes][n_samples], or NULL: staging + callback */
+  std::mutex mu;
+  std::condition_variable cv_work, cv_free;
+  std::deque<Block> work;
+  int pending[2];          /* blocks of the chunk in d_out[k] not delivered yet */
+  bool closing;
+  std::atomic<int> rc;     /* first failure: VS_ERR_*; callbacks' non-zero becomes VS_ERR_IO */
+  int hip_error;
+};
+
+void worker(Pipe *p, int t)
+{
+  vs_ctx *ctx = p->ctx;
+  VsPool &P = ctx->pool;
+  if (hipSetDevice(ctx->device) != hipSuccess) {
+    int ok = VS_OK;
+    p->rc.compare_exchange_strong(ok, VS_ERR_HIP);
+  }
+  for (;;) {
+    Block b;
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv_work.wait(lk, [&] { return !p->work.empty() || p->closing; });
+      if (p->work.empty()) return;
+      b = p->work.front();
+      p->work.pop_front();
+    }
+    if (p->rc.load() == VS_OK) {
+      const int16_t *src = (const int16_t *)P.d_out[b.buf] + (b.row0 - b.buf_row0) * p->pitch;
+      int16_t *dst = p->direct ? p->direct + b.row0 * p->n_samples : (int16_t *)P.staging[t];
+      hipError_t e = hipStreamWaitEvent(P.copy_stream[t], P.done[b.buf], 0);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(dst, p->n_samples * 2, src, p->pitch * 2, p->n_samples * 2, b.rows,
+                             hipMemcpyDeviceToHost, P.copy_stream[t]);
+      if (e == hipSuccess) e = hipStreamSynchronize(P.copy_stream[t]);
+      if (e != hipSuccess) {
+        int ok = VS_OK;
+        if (p->rc.compare_exchange_strong(ok, VS_ERR_HIP)) p->hip_error = (int)e;
+      } else if (p->cb && p->cb(p->user, b.row0, b.rows, dst) != 0) {
+        int ok = VS_OK;
+        p->rc.compare_exchange_strong(ok, VS_ERR_IO);
+      }
+    }
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      p->pending[b.buf]--;
+    }
+    p->cv_free.notify_all();
+  }
+}
+
+}  // namespace
+
+static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                              vs_rows_cb cb, void *user, int16_t *direct)
+{
+  if (!ctx || !lanes || n_lanes == 0 || n_samples == 0 || (!cb && !direct)) return VS_ERR_ARG;
+  if (n_samples * sizeof(int16_t) > VS_STAGING_BYTES && !direct) return VS_ERR_UNSUPPORTED; /* one row per block at least */
+  int rc = vs_pool_streams(ctx);
+  if (rc != VS_OK) return rc;
+  VsPool &P = ctx->pool;
+  const size_t pitch = (n_samples + 7) & ~(size_t)7; /* device rows start 16-byte aligned */
+  const size_t chunk = std::min<size_t>(n_lanes, VS_COMPUTE_CHUNK);
+  for (int k = 0; k < 2 && (k == 0 || n_lanes > chunk); k++) {
+    rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
+    if (rc != VS_OK) return rc;
+  }
+  size_t rows_per_block = VS_STAGING_BYTES / (n_samples * sizeof(int16_t));
+  if (rows_per_block < 1) rows_per_block = 1;
+  if (direct) rows_per_block = std::max<size_t>(rows_per_block, 1024); /* no staging limit: fewer, larger DMAs */
+
+  Pipe pipe;
+  pipe.ctx = ctx;
+  pipe.n_samples = n_samples;
+  pipe.pitch = pitch;
+  pipe.cb = cb;
+  pipe.user = user;
+  pipe.direct = direct;
+  pipe.pending[0] = pipe.pending[1] = 0;
+  pipe.closing = false;
+  pipe.rc.store(VS_OK);
+  pipe.hip_error = 0;
+  std::vector<std::thread> th;
+  try {
+    for (int t = 0; t < VS_DELIVERY_THREADS; t++) th.emplace_back(worker, &pipe, t);
+  } catch (...) {
+    {
+      std::lock_guard<std::mutex> lk(pipe.mu);
+      pipe.closing = true;
+    }
+    pipe.cv_work.notify_all();
+    for (auto &x : th) x.join();
+    return VS_ERR_NOMEM;
+  }
+
+  /* the caller's stream if there is one (its work is ordered before ours), else the context's own */
+  hipStream_t cs = ctx->stream ? ctx->stream : P.compute_stream;
+  hipStream_t saved = ctx->stream;
+  ctx->stream = cs; /* vs_plan_create / vs_plan_launch issue on the context's stream */
+  std::vector<vs_plan *> plans;
+  int k = 0;
+  for (size_t row0 = 0; row0 < n_lanes && pipe.rc.load() == VS_OK; row0 += chunk, k ^= 1) {
+    const size_t rows = std::min(chunk, n_lanes - row0);
+    vs_plan *plan = nullptr;
+    rc = vs_plan_create_impl(ctx, lanes + row0, rows, n_samples, 0, &plan); /* host work, overlaps the device */
+    if (rc != VS_OK) break;
+    plans.push_back(plan);
+    {
+      /* the buffer this chunk goes into must have been delivered */
+      std::unique_lock<std::mutex> lk(pipe.mu);
+      pipe.cv_free.wait(lk, [&] { return pipe.pending[k] == 0; });
+    }
+    rc = vs_plan_launch(plan, VS_KIND_SYNTH, nullptr, 0, (int16_t *)P.d_out[k], pitch, nullptr, 0, nullptr);
+    if (rc != VS_OK) break;
+    hipError_t e = hipEventRecord(P.done[k], cs);
+    if (e != hipSuccess) {
+      ctx->last_hip_error = (int)e;
+      rc = VS_ERR_HIP;
+      break;
+    }
+    {
+      std::lock_guard<std::mutex> lk(pipe.mu);
+      for (size_t r = 0; r < rows; r += rows_per_block) {
+        Block b;
+        b.row0 = row0 + r;
+        b.rows = std::min(rows_per_block, rows - r);
+        b.buf = k;
+        b.buf_row0 = row0;
+        pipe.work.push_back(b);
+        pipe.pending[k]++;
+      }
+    }
+    pipe.cv_work.notify_all();
+  }
+  {
+    std::unique_lock<std::mutex> lk(pipe.mu);
+    pipe.cv_free.wait(lk, [&] { return pipe.pending[0] == 0 && pipe.pending[1] == 0; });
+    pipe.closing = true;
+  }
+  pipe.cv_work.notify_all();
+  for (auto &x : th) x.join();
+  if (rc == VS_OK && pipe.rc.load() != VS_OK) {
+    rc = pipe.rc.load();
+    if (rc == VS_ERR_HIP) ctx->last_hip_error = pipe.hip_error;
+  }
+  /* the launches' health words (bounded waits of the wave-specialised kernel), then the plans */
+  for (vs_plan *pl : plans) {
+    const int st = vs_plan_status(pl, nullptr);
+    if (rc == VS_OK && st != VS_OK) rc = st;
+  }
+  for (vs_plan *pl : plans) vs_plan_destroy(pl);
+  ctx->stream = saved;
+  return rc;
+}
+
+extern "C" int vs_synth_rows(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                             vs_rows_cb cb, void *user)
+{
+  if (!cb) return VS_ERR_ARG;
+  return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, cb, user, nullptr);
+}
+
+namespace {
+struct CopyOut {
+  int16_t *pcm;
+  size_t n_samples;
+};
+int copy_rows(void *user, size_t row0, size_t rows, const int16_t *pcm)
+{
+  CopyOut *c = (CopyOut *)user;
+  memcpy(c->pcm + row0 * c->n_samples, pcm, rows * c->n_samples * sizeof(int16_t));
+  return 0;
+}
+}  // namespace
+
+extern "C" int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                        int16_t *pcm)
+{
+  if (!pcm) return VS_ERR_ARG;
+  if (vs_is_pinned(pcm)) /* DMA straight into the caller's buffer */
+    return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, nullptr, nullptr, pcm);
+  CopyOut c = {pcm, n_samples};
+  return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, copy_rows, &c, nullptr);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * vs_source / vs_filter: what the two drop-in programs call (one utterance, or small batches)
+ * ---------------------------------------------------------------------------------------- */
+static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lanes,
+                       size_t n_samples, const int16_t *in_host, int16_t *out_host,
+                       vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
+{
+  if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
+  VsPool &P = ctx->pool;
+  vs_plan *plan = nullptr;
+  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, kind == VS_KIND_FILTER, &plan);
+  if (rc != VS_OK) return rc;
+  const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
+  const size_t bytes = n_lanes * pitch * sizeof(int16_t);
+  const bool want_log = recs && kind != VS_KIND_FILTER;
+  const bool want_ncyc = ncyc && kind != VS_KIND_FILTER;
+  const size_t log_bytes = want_log ? n_lanes * recs_pitch * sizeof(vs_cycle_rec) : 0;
+  const size_t ncyc_bytes = want_ncyc ? n_lanes * sizeof(int32_t) : 0;
+  rc = vs_pool_device(ctx, &P.d_out[0], &P.d_out_bytes[0], bytes);
+  if (rc == VS_OK && kind == VS_KIND_FILTER) rc = vs_pool_device(ctx, &P.d_in, &P.d_in_bytes, bytes);
+  if (rc == VS_OK && (log_bytes || ncyc_bytes)) rc = vs_pool_device(ctx, &P.d_aux, &P.d_aux_bytes, log_bytes + ncyc_bytes + 16);
+  if (rc != VS_OK) {
+    vs_plan_destroy(plan);
+    return rc;
+  }
+  int16_t *d_out = (int16_t *)P.d_out[0];
+  int16_t *d_in = (kind == VS_KIND_FILTER) ? (int16_t *)P.d_in : nullptr;
+  vs_cycle_rec *d_log = want_log ? (vs_cycle_rec *)P.d_aux : nullptr;
+  int32_t *d_ncyc = want_ncyc ? (int32_t *)((char *)P.d_aux + ((log_bytes + 15) & ~(size_t)15)) : nullptr;
+  hipError_t e = hipSuccess;
+  if (d_in)
+    e = hipMemcpy2DAsync(d_in, pitch * 2, in_host, n_samples * 2, n_samples * 2, n_lanes,
+                         hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && d_log) e = hipMemsetAsync(d_log, 0, log_bytes, ctx->stream);
+  if (e == hipSuccess) {
+    rc = vs_plan_launch(plan, kind, d_in, pitch, d_out, pitch, d_log, recs_pitch, d_ncyc);
+    if (rc == VS_OK)
+      e = hipMemcpy2DAsync(out_host, n_samples * 2, d_out, pitch * 2, n_samples * 2, n_lanes,
+                           hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == VS_OK && e == hipSuccess && d_log)
+      e = hipMemcpyAsync(recs, d_log, log_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (rc == VS_OK && e == hipSuccess && d_ncyc)
+      e = hipMemcpyAsync(ncyc, d_ncyc, ncyc_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && rc == VS_OK) rc = vs_plan_status(plan, nullptr);
+  }
+  vs_plan_destroy(plan);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    return VS_ERR_HIP;
+  }
+  return rc;
+}
+
+extern "C" int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         int16_t *flow, vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
+{
+  if (recs && recs_pitch == 0) return VS_ERR_ARG;
+  return vs_run_host(ctx, VS_KIND_SOURCE, lanes, n_lanes, n_samples, nullptr, flow, recs,
+                     recs_pitch, ncyc);
+}
+
+extern "C" int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         const int16_t *flow, int16_t *pcm)
+{
+  if (!flow) return VS_ERR_ARG;
+  return vs_run_host(ctx, VS_KIND_FILTER, lanes, n_lanes, n_samples, flow, pcm, nullptr, 0,
+                     nullptr);
+}

@@ -1,0 +1,85 @@
+/*
+ * vs_internal.h -- what the translation units of libvoicesynth share behind the C ABI:
+ * the context and plan records, the context's buffer pool, internal entry points.
+ */
+#ifndef VS_INTERNAL_H
+#define VS_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/voice_synth.h"
+#include "vs_device.h"
+
+#define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
+#define VS_DELIVERY_THREADS 4     /* row-chunk delivery workers (each: one stream + one pinned staging buffer) */
+#define VS_STAGING_BYTES (16u << 20)
+
+/* Buffers a context keeps between calls (grown on demand, freed by vs_ctx_destroy or
+ * vs_ctx_trim): nothing on the host-buffer paths calls hipMalloc / hipHostMalloc per call. */
+struct VsPool {
+  void *d_out[2];           /* device PCM of the compute chunk in flight / being delivered */
+  size_t d_out_bytes[2];
+  void *d_in;               /* filter-only kind: the uploaded flow */
+  size_t d_in_bytes;
+  void *d_aux;              /* cycle log + cycle counts of vs_source */
+  size_t d_aux_bytes;
+  void *staging[VS_DELIVERY_THREADS]; /* pinned host memory, VS_STAGING_BYTES each */
+  hipStream_t copy_stream[VS_DELIVERY_THREADS];
+  hipStream_t compute_stream; /* compute chunks of vs_synth_rows when the caller set no stream */
+  hipEvent_t done[2];       /* kernel of the chunk in d_out[k] has finished */
+  int streams_ready;
+};
+
+struct vs_ctx {
+  int device;
+  int arith;
+  hipStream_t stream;
+  int last_hip_error;
+  char name[128];
+  int cu_count;
+  vs_tuning tuning; /* all zero = the library's own choices */
+  VsPool pool;
+};
+
+struct vs_plan {
+  vs_ctx *ctx;
+  size_t n_lanes, n_samples;
+  VsDevLane *d_lanes;
+  double *d_costab;
+  int ring_slots;
+  int ready_min;
+  int ltab_entries;
+  size_t lds_bytes;
+  unsigned grid;
+  unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
+  int *d_err;                 /* spin-limit word of the wave-specialised kernel */
+  float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
+  long opow_pitch;
+  int wave_specialised;
+  int ws_pairs;      /* generator/filter pairs per workgroup of the wave-specialised launch */
+  int ws_pair_bytes; /* LDS bytes of one pair */
+  int filter_only;   /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
+  int pre1;          /* every lane has pre_emphasis == 1.0 (the reference's default) */
+  vs_tuning tuning;  /* the context's tuning when the plan was made */
+  double host_ms;    /* host time of vs_plan_create: expansion, sorting, tables */
+  double upload_ms;  /* ... and of the allocation + upload + wait that follows */
+};
+
+#define VS_HIP(ctx, call)                        \
+  do {                                           \
+    hipError_t e_ = (call);                      \
+    if (e_ != hipSuccess) {                      \
+      (ctx)->last_hip_error = (int)e_;           \
+      return VS_ERR_HIP;                         \
+    }                                            \
+  } while (0)
+
+int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                        int filter_only, vs_plan **out);
+/* grows *ptr (device memory) to at least bytes; VS_OK or VS_ERR_HIP */
+int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes);
+/* creates the delivery streams, events and pinned staging buffers on first use */
+int vs_pool_streams(vs_ctx *ctx);
+void vs_pool_release(vs_ctx *ctx);
+
+#endif

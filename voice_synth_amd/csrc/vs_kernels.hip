@@ -425,11 +425,23 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
   /* ---- rising half-pulse: fg:318-324 ---- */
   if (fast) {
     const float dcs2 = dcsf * dcsf;
+    /* the cos values of trip i+8 are read while trip i computes: one wavefront per SIMD has
+     * nothing else to put behind an LDS round trip */
+    double cv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cv[k] = trow[k];
     for (int i = 0; __any(i < T2); i += 8) {
       if (i < T2) {
+        double nv[8];
+        if (i + 8 < T2) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) nv[k] = trow[i + 8 + k];
+        }
         int x[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ah * (1.0 - trow[i + k])); /* pad: cos = 1 -> 0 */
+        for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ah * (1.0 - cv[k])); /* pad: cos = 1 -> 0 */
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv[k] = nv[k];
         const VsRun8 run = vs_run8(ring, s.wpos, C, i, lane);
         /* monotone flank: if the trip's first sample is not below DC none of it is */
         if (__any(x[0] < c.thr)) {
@@ -503,12 +515,24 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
       /* whole trips of 8 (k0 + 8 <= T2); the flank falls monotonically, so a trip whose last
        * sample is not below DC holds no break.  Stores are unconditional: slots at and behind
        * the break are written again by the closed phase (2*T2 + 8 <= T). */
+      double cv[8];
+      if (8 <= T2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cv[k] = trow[k];
+      }
       for (int k0 = 0; __any(run && (k0 + 8 <= T2)); k0 += 8) {
         if (run && (k0 + 8 <= T2)) {
           kdone = k0 + 8;
+          double nv[8];
+          if (k0 + 16 <= T2) { /* next trip's cos values, read behind this trip's arithmetic */
+#pragma unroll
+            for (int k = 0; k < 8; ++k) nv[k] = trow[k0 + 8 + k];
+          }
           int x[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ad * ((Kd * trow[k0 + k] - Kd) + 1.0));
+          for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ad * ((Kd * cv[k] - Kd) + 1.0));
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cv[k] = nv[k];
           const VsRun8 r8 = vs_run8(ring, s.wpos, C, T2 + k0, lane);
           if (__any(x[7] < c.thr)) {
 #pragma unroll

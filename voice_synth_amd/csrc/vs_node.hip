@@ -1,0 +1,323 @@
+/*
+ * vs_node.hip -- one batch over the GPUs of one node, in C (north star: "host code stays in C";
+ * SURVEY.md section 8b/8e).
+ *
+ * Utterances are independent -- all carried state of the reference is per utterance
+ * (flowgen_shimmer.c:121-122, vowel_new.c:90) -- so a batch is cut into contiguous blocks of
+ * lanes, one block ("shard") per device, with NO data-path collective.  A lane's draw stream is
+ * keyed by the seed in its own vs_lane record, so the result does not depend on the placement:
+ * N shards give byte for byte what one device gives.
+ *
+ * The one exchange the north star names is the delivery of the finished PCM:
+ *   vs_node_synth_gather  into device 0's HBM.  Every shard synthesises its block in chunks of
+ *                         VS_NODE_CHUNK utterances; a finished chunk is copied to its place in the
+ *                         root buffer by a peer DMA (hipMemcpy2DAsync between devices = one stream
+ *                         per xGMI link into the root, the pattern SURVEY.md section 5 asks for:
+ *                         7 concurrent point-to-point transfers, no ring) on the shard's copy
+ *                         stream while its next chunk is being synthesised on its compute stream.
+ *                         The root's own shard is synthesised in place.
+ *   vs_node_synth_rows    to the host: every shard runs the pipeline of vs_synth_rows() on its own
+ *                         device and PCIe link; the callback sees global row numbers.
+ * A device may appear several times in the device list ("logical shards"): that is how the
+ * N-device path is tested on a box with one GPU.
+ *
+ * One host thread per shard (a vs_ctx is used by one thread at a time).  The multi-PROCESS form
+ * of the same scheme -- one rank per GPU under torch.distributed.run, RCCL send/recv of the
+ * chunks -- is what bench.py --gpus N runs; see voice_synth_amd/dist.py.
+ */
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "vs_internal.h"
+
+#define VS_NODE_CHUNK 16384
+
+struct vs_node {
+  std::vector<vs_ctx *> ctx;   /* one per shard */
+  std::vector<int> device;
+  std::vector<hipStream_t> compute, copy;
+  std::vector<hipEvent_t> ev_done[2], ev_copied[2];
+};
+
+extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
+{
+  if (!devices || n_shards <= 0 || n_shards > 64 || !out) return VS_ERR_ARG;
+  *out = nullptr;
+  vs_node *nd = new (std::nothrow) vs_node();
+  if (!nd) return VS_ERR_NOMEM;
+  int rc = VS_OK;
+  for (int s = 0; s < n_shards && rc == VS_OK; s++) {
+    vs_ctx *c = nullptr;
+    rc = vs_ctx_create(devices[s], &c);
+    if (rc != VS_OK) break;
+    nd->ctx.push_back(c);
+    nd->device.push_back(devices[s]);
+    hipStream_t a = nullptr, b = nullptr;
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t he = hipSetDevice(devices[s]);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+    for (int k = 0; k < 4 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&e[k], hipEventDisableTiming);
+    nd->compute.push_back(a);
+    nd->copy.push_back(b);
+    nd->ev_done[0].push_back(e[0]);
+    nd->ev_done[1].push_back(e[1]);
+    nd->ev_copied[0].push_back(e[2]);
+    nd->ev_copied[1].push_back(e[3]);
+    if (he != hipSuccess) rc = VS_ERR_HIP;
+    /* the root must be reachable by peer DMA from every other device */
+    if (rc == VS_OK && devices[s] != devices[0]) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[s], devices[0]) == hipSuccess && can) {
+        he = hipDeviceEnablePeerAccess(devices[0], 0);
+        if (he != hipSuccess && he != hipErrorPeerAccessAlreadyEnabled) rc = VS_ERR_HIP;
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (rc != VS_OK) {
+    vs_node_destroy(nd);
+    return rc;
+  }
+  *out = nd;
+  return VS_OK;
+}
+
+extern "C" void vs_node_destroy(vs_node *nd)
+{
+  if (!nd) return;
+  for (size_t s = 0; s < nd->ctx.size(); s++) {
+    (void)hipSetDevice(nd->device[s]);
+    if (s < nd->compute.size() && nd->compute[s]) (void)hipStreamDestroy(nd->compute[s]);
+    if (s < nd->copy.size() && nd->copy[s]) (void)hipStreamDestroy(nd->copy[s]);
+    for (int k = 0; k < 2; k++) {
+      if (s < nd->ev_done[k].size() && nd->ev_done[k][s]) (void)hipEventDestroy(nd->ev_done[k][s]);
+      if (s < nd->ev_copied[k].size() && nd->ev_copied[k][s]) (void)hipEventDestroy(nd->ev_copied[k][s]);
+    }
+    vs_ctx_destroy(nd->ctx[s]);
+  }
+  delete nd;
+}
+
+extern "C" int vs_node_shards(const vs_node *nd) { return nd ? (int)nd->ctx.size() : 0; }
+
+extern "C" int vs_node_ctx(vs_node *nd, int shard, vs_ctx **ctx)
+{
+  if (!nd || !ctx || shard < 0 || shard >= (int)nd->ctx.size()) return VS_ERR_ARG;
+  *ctx = nd->ctx[(size_t)shard];
+  return VS_OK;
+}
+
+extern "C" int vs_node_set_arith(vs_node *nd, int arith)
+{
+  if (!nd) return VS_ERR_ARG;
+  for (vs_ctx *c : nd->ctx) {
+    const int rc = vs_ctx_set_arith(c, arith);
+    if (rc != VS_OK) return rc;
+  }
+  return VS_OK;
+}
+
+/* lanes [lo, hi) of shard s: contiguous blocks of ceil(n / shards) */
+static void shard_range(size_t n_lanes, size_t shards, size_t s, size_t *lo, size_t *hi)
+{
+  const size_t per = (n_lanes + shards - 1) / shards;
+  *lo = std::min(n_lanes, s * per);
+  *hi = std::min(n_lanes, *lo + per);
+}
+
+extern "C" int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard, size_t *lo, size_t *hi)
+{
+  if (!nd || !lo || !hi || shard < 0 || shard >= (int)nd->ctx.size()) return VS_ERR_ARG;
+  shard_range(n_lanes, nd->ctx.size(), (size_t)shard, lo, hi);
+  return VS_OK;
+}
+
+namespace {
+struct ShardJob {
+  vs_node *nd;
+  size_t s;
+  const vs_lane *lanes;
+  size_t lo, hi, n_samples;
+  int16_t *root;      /* device pointer on device[0]: int16 [n_lanes][root_pitch] */
+  size_t root_pitch;
+  int flags;          /* VS_NODE_OVERLAP, VS_NODE_STAGE_ALL */
+  int rc;
+  double compute_ms;  /* host clock: first launch .. last kernel done */
+};
+
+void shard_gather(ShardJob *j)
+{
+  vs_node *nd = j->nd;
+  const size_t s = j->s;
+  vs_ctx *ctx = nd->ctx[s];
+  j->rc = VS_OK;
+  j->compute_ms = 0.0;
+  if (j->lo >= j->hi) return;
+  if (hipSetDevice(nd->device[s]) != hipSuccess) {
+    j->rc = VS_ERR_HIP;
+    return;
+  }
+  VsPool &P = ctx->pool;
+  const size_t rows_all = j->hi - j->lo;
+  const size_t chunk = std::min<size_t>(rows_all, VS_NODE_CHUNK);
+  const size_t pitch = (j->n_samples + 7) & ~(size_t)7;
+  /* the root's own shard is synthesised in place when the destination rows allow 16-byte stores */
+  const bool in_place = (nd->device[s] == nd->device[0]) && !(j->flags & VS_NODE_STAGE_ALL);
+  if (!in_place) {
+    for (int k = 0; k < 2 && (k == 0 || rows_all > chunk); k++) {
+      j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
+      if (j->rc != VS_OK) return;
+    }
+  }
+  hipStream_t saved = ctx->stream;
+  ctx->stream = nd->compute[s];
+  std::vector<vs_plan *> plans;
+  struct Pending { size_t row0, rows; int k; };
+  std::vector<Pending> later;
+  const auto t0 = std::chrono::steady_clock::now();
+  int k = 0;
+  bool used[2] = {false, false};
+  for (size_t r0 = j->lo; r0 < j->hi && j->rc == VS_OK; r0 += chunk, k ^= 1) {
+    const size_t rows = std::min(chunk, j->hi - r0);
+    vs_plan *plan = nullptr;
+    j->rc = vs_plan_create_impl(ctx, j->lanes + r0, rows, j->n_samples, 0, &plan);
+    if (j->rc != VS_OK) break;
+    plans.push_back(plan);
+    int16_t *dst = j->root + r0 * j->root_pitch;
+    if (in_place) {
+      j->rc = vs_plan_launch(plan, VS_KIND_SYNTH, nullptr, 0, dst, j->root_pitch, nullptr, 0, nullptr);
+      continue;
+    }
+    /* the buffer must have been copied out before it is overwritten */
+    hipError_t e = hipSuccess;
+    if (used[k]) e = hipStreamWaitEvent(nd->compute[s], nd->ev_copied[k][s], 0);
+    if (e == hipSuccess) {
+      j->rc = vs_plan_launch(plan, VS_KIND_SYNTH, nullptr, 0, (int16_t *)P.d_out[k], pitch, nullptr, 0, nullptr);
+      if (j->rc != VS_OK) break;
+      e = hipEventRecord(nd->ev_done[k][s], nd->compute[s]);
+    }
+    if (e == hipSuccess && (j->flags & VS_NODE_OVERLAP)) {
+      e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P.d_out[k], pitch * 2, j->n_samples * 2, rows,
+                             hipMemcpyDefault, nd->copy[s]);
+      if (e == hipSuccess) e = hipEventRecord(nd->ev_copied[k][s], nd->copy[s]);
+      used[k] = true;
+    } else if (e == hipSuccess) {
+      /* un-overlapped: this chunk's copy is issued behind ALL kernels; with more than two chunks
+       * the two buffers force a wait here, which is the point of the comparison */
+      e = hipStreamSynchronize(nd->compute[s]);
+      if (e == hipSuccess)
+        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P.d_out[k], pitch * 2, j->n_samples * 2, rows,
+                             hipMemcpyDefault, nd->copy[s]);
+      if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
+    }
+    if (e != hipSuccess) {
+      ctx->last_hip_error = (int)e;
+      j->rc = VS_ERR_HIP;
+    }
+  }
+  hipError_t e = hipStreamSynchronize(nd->compute[s]);
+  j->compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
+  if (e != hipSuccess && j->rc == VS_OK) {
+    ctx->last_hip_error = (int)e;
+    j->rc = VS_ERR_HIP;
+  }
+  for (vs_plan *pl : plans) {
+    const int st = vs_plan_status(pl, nullptr);
+    if (j->rc == VS_OK && st != VS_OK) j->rc = st;
+  }
+  for (vs_plan *pl : plans) vs_plan_destroy(pl);
+  ctx->stream = saved;
+}
+}  // namespace
+
+extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                                    int16_t *root_dev, size_t root_pitch, int flags, double *total_ms,
+                                    double *max_compute_ms)
+{
+  if (!nd || !lanes || !root_dev || n_lanes == 0 || n_samples == 0 || root_pitch < n_samples) return VS_ERR_ARG;
+  const size_t S = nd->ctx.size();
+  std::vector<ShardJob> jobs(S);
+  std::vector<std::thread> th;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t s = 0; s < S; s++) {
+    ShardJob &j = jobs[s];
+    j.nd = nd;
+    j.s = s;
+    j.lanes = lanes;
+    shard_range(n_lanes, S, s, &j.lo, &j.hi);
+    j.n_samples = n_samples;
+    j.root = root_dev;
+    j.root_pitch = root_pitch;
+    j.flags = flags;
+    j.rc = VS_OK;
+  }
+  try {
+    for (size_t s = 0; s < S; s++) th.emplace_back(shard_gather, &jobs[s]);
+  } catch (...) {
+    for (auto &x : th) x.join();
+    return VS_ERR_NOMEM;
+  }
+  for (auto &x : th) x.join();
+  if (total_ms) *total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  double mc = 0.0;
+  int rc = VS_OK;
+  for (size_t s = 0; s < S; s++) {
+    mc = std::max(mc, jobs[s].compute_ms);
+    if (rc == VS_OK && jobs[s].rc != VS_OK) rc = jobs[s].rc;
+  }
+  if (max_compute_ms) *max_compute_ms = mc;
+  return rc;
+}
+
+namespace {
+struct RowsShift {
+  vs_rows_cb cb;
+  void *user;
+  size_t lo;
+};
+int shifted(void *u, size_t row0, size_t rows, const int16_t *pcm)
+{
+  RowsShift *r = (RowsShift *)u;
+  return r->cb(r->user, r->lo + row0, rows, pcm);
+}
+}  // namespace
+
+extern "C" int vs_node_synth_rows(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                                  vs_rows_cb cb, void *user)
+{
+  if (!nd || !lanes || !cb || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
+  const size_t S = nd->ctx.size();
+  std::vector<int> rcs(S, VS_OK);
+  std::vector<RowsShift> sh(S);
+  std::vector<std::thread> th;
+  try {
+    for (size_t s = 0; s < S; s++) {
+      size_t lo, hi;
+      shard_range(n_lanes, S, s, &lo, &hi);
+      if (lo >= hi) continue;
+      sh[s].cb = cb;
+      sh[s].user = user;
+      sh[s].lo = lo;
+      th.emplace_back([=, &rcs, &sh]() {
+        rcs[s] = vs_synth_rows(nd->ctx[s], lanes + lo, hi - lo, n_samples, shifted, &sh[s]);
+      });
+    }
+  } catch (...) {
+    for (auto &x : th) x.join();
+    return VS_ERR_NOMEM;
+  }
+  for (auto &x : th) x.join();
+  for (size_t s = 0; s < S; s++)
+    if (rcs[s] != VS_OK) return rcs[s];
+  return VS_OK;
+}
