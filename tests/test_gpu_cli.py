@@ -77,6 +77,23 @@ def test_vs_batch_manifest(tmp_path):
         assert sha(raw[44:]) == CASES[n]["sha256_pcm"], n
 
 
+def test_vs_batch_sharded_over_logical_devices(tmp_path):
+    """vs_batch --gpus 4 with VS_DEVICES=0,0,0,0: four logical shards of the one device, each a
+    contiguous block of the manifest; the files must not depend on the sharding"""
+    names = ["cfg3_lane0", "cfg3_lane1", "cfg3_lane2", "cfg2_lane0", "cfg2_lane1", "ka_g16_va", "cfg5_lane3"]
+    names = [n for n in names if n in CASES and CASES[n]["n_samples"] == 16000]
+    assert len(names) >= 5
+    lines = ["seed=%d -o s%d.wav %s | %s" % (CASES[n]["seed"], i, " ".join(CASES[n]["flowgen_args"]), " ".join(CASES[n]["vowel_args"]))
+             for i, n in enumerate(names)]
+    (tmp_path / "m.txt").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([os.path.join(BIN, "vs_batch"), "--gpus", "4", "m.txt"], cwd=tmp_path, capture_output=True,
+                       env=dict(os.environ, VS_WAV_HEADER="44", VS_DEVICES="0,0,0,0"))
+    assert r.returncode == 0, r.stderr
+    for i, n in enumerate(names):
+        raw = open(tmp_path / ("s%d.wav" % i), "rb").read()
+        assert sha(raw[44:]) == CASES[n]["sha256_pcm"], n
+
+
 def test_vs_batch_rejects_what_the_reference_rejects(tmp_path):
     (tmp_path / "m.txt").write_text("-o a.wav -r 22050 | -v a\n")     # explicit 22050 (SURVEY F7)
     r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True)

@@ -3,7 +3,10 @@
  * described by the REFERENCE's own command lines, synthesised in one fused GPU launch per
  * distinct sample count, written as N .wav files.
  *
- *     vs_batch manifest.txt
+ *     vs_batch [--gpus N] manifest.txt
+ *
+ * --gpus N shards every launch over devices 0..N-1 (contiguous blocks of utterances, one host
+ * thread and one PCIe link per device: vs_node_synth_rows).
  *
  * One utterance per manifest line:
  *
@@ -17,6 +20,11 @@
  * use, so ranges, defaults and quirks are the reference's.  Without "seed=" a line's Philox key
  * is VS_SEED (default: time) + line number.  Empty lines and lines starting with '#' are
  * skipped.  Exit code 0 on success, 1 on any error (nothing is exit()ed from the library).
+ *
+ * Output path (what replaces the fwrite()s of flowgen_shimmer.c:413-421 and vowel_new.c:327): the
+ * files are written from the pinned staging blocks of vs_synth_rows() by the library's delivery
+ * threads -- header, then payload -- while the device is synthesising the next chunk of the
+ * batch and the DMA engines are moving the next blocks; there is no batch-sized host buffer.
  */
 #include <ctype.h>
 
@@ -45,10 +53,48 @@ static int split(char *s, char **tok, int max)
   return n;
 }
 
+/* one launch's worth of files: rows of the launch -> jobs */
+typedef struct {
+  job *jobs;
+  const size_t *index;
+  uint64_t ns;
+  int header_bytes;
+  volatile int failed;
+} sink;
+
+/* vs_rows_cb: called from the delivery threads, concurrently for different blocks (distinct
+ * files, so no locking) */
+static int write_rows(void *user, size_t row0, size_t rows, const int16_t *pcm)
+{
+  sink *sk = (sink *)user;
+  for (size_t r = 0; r < rows; r++) {
+    job *j = &sk->jobs[sk->index[row0 + r]];
+    unsigned char header[72];
+    const int hbytes = vs_wav_header_write(header, sk->header_bytes, j->lane.fs, j->dur);
+    FILE *f = fopen(j->path, "wb");
+    if (!f || hbytes <= 0 || fwrite(header, (size_t)hbytes, 1, f) != 1 ||
+        fwrite(pcm + r * (size_t)sk->ns, sizeof(int16_t), (size_t)sk->ns, f) != (size_t)sk->ns) {
+      fprintf(stderr, "vs_batch: cannot write %s\n", j->path);
+      if (f) fclose(f);
+      sk->failed = 1;
+      return 1;
+    }
+    fclose(f);
+    j->done = 1;
+  }
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
-  if (argc != 2) {
-    fprintf(stderr, "usage: vs_batch manifest.txt\n"
+  int gpus = 1;
+  if (argc == 4 && strcmp(argv[1], "--gpus") == 0) {
+    gpus = atoi(argv[2]);
+    argv += 2;
+    argc -= 2;
+  }
+  if (argc != 2 || gpus < 1 || gpus > 64) {
+    fprintf(stderr, "usage: vs_batch [--gpus N] manifest.txt\n"
                     "  line: [seed=N] <flowgen_shimmer args incl. -o out.wav> | <vowel args: -v x [-g x] [-p x] [-n x]>\n");
     return 1;
   }
@@ -130,7 +176,28 @@ int main(int argc, char **argv)
   }
 
   vs_ctx *ctx = NULL;
-  if (vs_cli_open_ctx(&ctx) != VS_OK) return 1;
+  vs_node *node = NULL;
+  if (gpus == 1) {
+    if (vs_cli_open_ctx(&ctx) != VS_OK) return 1;
+  } else {
+    /* devices 0..N-1, or the ordinals listed in VS_DEVICES ("0,0,0,0": logical shards of one
+     * device, how the sharded path is exercised on a one-GPU box) */
+    int devs[64];
+    for (int d = 0; d < gpus; d++) devs[d] = d;
+    const char *list = getenv("VS_DEVICES");
+    for (int d = 0; list && *list && d < gpus; d++) {
+      devs[d] = atoi(list);
+      const char *c = strchr(list, ',');
+      list = c ? c + 1 : NULL;
+    }
+    int rc = vs_node_create(devs, gpus, &node);
+    if (rc != VS_OK) {
+      fprintf(stderr, "vs_batch: cannot open %d GPU devices: %s\n", gpus, vs_strerror(rc));
+      return 1;
+    }
+    const char *a = getenv("VS_ARITH");
+    if (a && strcmp(a, "fma") == 0) vs_node_set_arith(node, VS_ARITH_FMA);
+  }
   const int hb = vs_cli_header_bytes();
   size_t remaining = n_jobs, launches = 0;
   vs_lane *lanes = (vs_lane *)malloc(n_jobs * sizeof(vs_lane));
@@ -147,34 +214,30 @@ int main(int argc, char **argv)
         index[m++] = k;
       }
     }
-    int16_t *pcm = (int16_t *)malloc(m * (size_t)ns * sizeof(int16_t));
-    if (!pcm) {
-      fprintf(stderr, "vs_batch: out of memory for %zu x %llu samples\n", m, (unsigned long long)ns);
-      return 1;
-    }
-    int rc = vs_synth(ctx, lanes, m, (size_t)ns, pcm);
-    if (rc != VS_OK) {
-      fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d)\n", vs_strerror(rc), vs_ctx_last_hip_error(ctx));
+    sink sk;
+    sk.jobs = jobs;
+    sk.index = index;
+    sk.ns = ns;
+    sk.header_bytes = hb;
+    sk.failed = 0;
+    int rc = node ? vs_node_synth_rows(node, lanes, m, (size_t)ns, write_rows, &sk)
+                  : vs_synth_rows(ctx, lanes, m, (size_t)ns, write_rows, &sk);
+    if (rc != VS_OK || sk.failed) {
+      if (!sk.failed)
+        fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d)\n", vs_strerror(rc), ctx ? vs_ctx_last_hip_error(ctx) : 0);
       return 1;
     }
     for (size_t q = 0; q < m; q++) {
-      job *j = &jobs[index[q]];
-      unsigned char header[72];
-      int hbytes = vs_wav_header_write(header, hb, j->lane.fs, j->dur);
-      FILE *f = fopen(j->path, "wb");
-      if (!f || fwrite(header, (size_t)hbytes, 1, f) != 1 ||
-          fwrite(pcm + q * (size_t)ns, sizeof(int16_t), (size_t)ns, f) != (size_t)ns) {
-        fprintf(stderr, "vs_batch: cannot write %s\n", j->path);
+      if (!jobs[index[q]].done) {
+        fprintf(stderr, "vs_batch: %s was not delivered\n", jobs[index[q]].path);
         return 1;
       }
-      fclose(f);
-      j->done = 1;
     }
-    free(pcm);
     remaining -= m;
     launches++;
   }
   printf("vs_batch: %zu utterances in %zu launch(es)\n", n_jobs, launches);
-  vs_ctx_destroy(ctx);
+  if (ctx) vs_ctx_destroy(ctx);
+  if (node) vs_node_destroy(node);
   return 0;
 }
