@@ -15,19 +15,28 @@ chip and is a parity case, not a throughput case; the north star's target is sta
 
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline     : algorithmic 2 B/sample over the kernel's mean duration (HIP events on the
-                 launch stream, inside the timed region) against the 8 TB/s HBM peak, plus the
-                 fp64-VALU view of the same kernel (the path is VALU-bound, DESIGN.md);
+                 launch stream, inside the timed region) against the 8 TB/s HBM peak; the
+                 fp64-VALU view of the same kernel (the path is VALU-issue-bound, DESIGN.md);
+                 `valu`: wave-instructions per sample and issue rate from the SQ counters
+                 committed under profiles/ for this kernel;
+  plan         : host cost of vs_plan_create for the batch (outside every timed region);
   cpu_baseline : the CPU oracle (kind "port", OpenMP over lanes) on this box's host cores, on a
-                 bounded sample of the same workload -- rank 0, N = 1 only;
-  gather       : N > 1 only -- the RCCL delivery of all PCM to rank 0, timed on its own AFTER
-                 the timed region (it is not part of `value`).
-The only use of oracle/ is inside cpu_baseline(): the CPU port is timed there, and its first
-rows are compared with the rows the GPU produced in the timed region.
+                 bounded sample of the same workload, and next to it the REFERENCE as shipped
+                 (oracle/_ref, -O0 as its Makefile builds it, and -O2; one process pair per
+                 utterance through .wav files, all host cores) -- rank 0, N = 1 only;
+  value_with_gather / gather : N > 1 only -- the same synthesis in chunks of 16384 utterances with
+                 every finished chunk travelling to rank 0 over RCCL while the next one is being
+                 synthesised (voice_synth_amd/dist.py::PipelinedGather), timed end to end AFTER
+                 the timed region; `value` itself leaves the PCM sharded.
+The only use of oracle/ is inside cpu_baseline(): the CPU port and the compiled reference are
+timed there, and the port's first rows are compared with the rows the GPU produced in the timed
+region.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,6 +47,8 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 GHz
 ALGO_BYTES_PER_SAMPLE = 2       # one int16 store; the flow never reaches HBM
 FLOP_PER_SAMPLE = 48            # 22 mul + 22 sub + gain + pre-emphasis mul/sub
+GATHER_CHUNK = 16384            # utterances per chunk of the pipelined gather
+GATHER_DEADLINE_S = 150         # the gather leg may not hold the benchmark line longer than this
 
 
 def parse_args():
@@ -54,6 +65,35 @@ def parse_args():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_as_shipped(specs, n_samples, opt, workers):
+    """oracle/_ref (the reference's own two programs, Philox random() shim) over `specs`: one
+    process pair per utterance through .wav files in a scratch directory, `workers` pairs in
+    flight -- what `xargs -P $(nproc)` would do with the reference as it ships."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import pyoracle as po
+
+    def one(spec):
+        fa, va, seed = spec
+        return po.run_reference(fa, va, seed, opt=opt)["pcm"]
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        pcms = list(ex.map(one, specs))
+    t = time.perf_counter() - t0
+    return pcms, t
+
+
 def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
     """The CPU oracle on a bounded sample of the same workload, all host cores.  The sample
     starts at lane 0, so its first rows double as a parity spot check of what the GPU just
@@ -62,8 +102,8 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
     import voice_synth_amd as vs
     from oracle import pyoracle as po
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, po.max_threads()))
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(host_cores, po.max_threads()))
     lanes_cal = 4 * cores
     lanes, _ = vs.lanes_from_specs(specs_fn(lanes_cal))
     t0 = time.perf_counter()
@@ -81,23 +121,26 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         "unit": "Msamples/s",
         "cores": cores,
         "kind": "port",
+        "cpu_model": _cpu_model(),
         "sample": "%d utterances x %d samples of the same workload (first lanes), %.1f s, OpenMP over lanes"
                   % (n_lanes, n_samples, t),
     }
     if po.have_reference():
-        # the reference AS SHIPPED (oracle/_ref: its own two programs, -O0, one process pair per
-        # utterance through .wav files, Philox shim), one core, a handful of utterances
-        specs = specs_fn(8)
-        t0 = time.perf_counter()
-        for fa, va, seed in specs:
-            ref = po.run_reference(fa, va, seed)
-        tr = time.perf_counter() - t0
-        out["reference_as_shipped"] = {
-            "value": round(len(specs) * n_samples / tr / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-            "sample": "%d utterances through oracle/_ref/flowgen_shimmer | vowel (-O0, file I/O and process start included), %.2f s"
-                      % (len(specs), tr),
-            "last_utterance_matches_port": bool(np.array_equal(ref["pcm"], pcm[len(specs) - 1])),
-        }
+        # the reference AS SHIPPED: its Makefile passes no -O flag (-O0); -O2 next to it.  One
+        # process pair per utterance, `workers` in flight, >= 4 utterances per worker.
+        workers = max(1, min(host_cores, 64))  # the GPU box caps the processes one command may run
+        specs = specs_fn(4 * workers)
+        shipped = {"workers": workers, "utterances": len(specs), "cpu_model": _cpu_model(),
+                   "how": "oracle/_ref/flowgen_shimmer | file | oracle/_ref/vowel per utterance, process start and file I/O included"}
+        for opt, key in (("", "O0_as_shipped"), ("O2", "O2")):
+            try:
+                pcms, tr = reference_as_shipped(specs, n_samples, opt, workers)
+                shipped[key] = {"value": round(len(specs) * n_samples / tr / 1e6, 2), "unit": "Msamples/s",
+                                "seconds": round(tr, 2),
+                                "matches_port": bool(all(np.array_equal(p, pcm[i]) for i, p in enumerate(pcms[:min(len(pcms), n_lanes)])))}
+            except Exception as exc:  # pragma: no cover - e.g. the -O2 build is absent
+                shipped[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        out["reference_as_shipped"] = shipped
     if gpu_first_lanes is not None:
         k = min(len(gpu_first_lanes), n_lanes)
         out["gpu_rows_checked"] = k
@@ -108,6 +151,16 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         out["gpu_rms_error_lsb"] = float(np.sqrt(np.mean(d * d)))
         out["gpu_rms_error_normalised"] = float(np.sqrt(np.mean((d / 32768.0) ** 2)))
     return out
+
+
+def _profile_record(name, key):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(key)
+        except Exception:
+            return None
+    return None
 
 
 def main():
@@ -126,7 +179,7 @@ def main():
 
     import voice_synth_amd as vs
     from voice_synth_amd import configs
-    from voice_synth_amd.dist import gather_pcm
+    from voice_synth_amd.dist import PipelinedGather, gather_pcm
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -149,6 +202,8 @@ def main():
     eng = vs.Engine(local_rank, arith=arith, stream=stream.cuda_stream)
     dev_name, cus = eng.device_info()
     plan = eng.plan(lanes, n_samples)                     # lane records + cos rows -> HBM
+    plan_host_ms, plan_upload_ms = plan.timing()
+    kernel_name = plan.kernel_name(vs.VS_KIND_SYNTH)
     out = torch.empty((per_gpu, pitch), dtype=torch.int16, device=dev)
 
     def launch():
@@ -172,6 +227,7 @@ def main():
         b.record(stream)
     sync_all()
     elapsed = time.perf_counter() - t0
+    health = plan.status()   # raises if a device-side bounded wait ran out in any of the launches
 
     kern_ms = [a.elapsed_time(b) for a, b in ev]
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -191,6 +247,7 @@ def main():
     # ---- the other arithmetic mode, outside the timed region (3 launches) ----
     other = vs.VS_ARITH_FMA if arith == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
     eng.set_arith(other)
+    other_kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
     launch()
     torch.cuda.synchronize(dev)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -199,53 +256,31 @@ def main():
         launch()
     b.record(stream)
     torch.cuda.synchronize(dev)
+    plan.status()
     other_ms = a.elapsed_time(b) / 3.0
     eng.set_arith(arith)
-
-    # ---- N > 1: delivery of the PCM to rank 0 over RCCL, timed on its own ----
-    gather = None
-    if world > 1 and not args.no_gather:
-        # optional delivery step: it must never cost the benchmark line, so failures are reported
-        try:
-            launch()
-            sync_all()
-            local = out[:, :n_samples]
-            # every rank must take the same decision, or the peers would wait for a root that
-            # gave up: rank 0 checks that the gathered PCM fits, the verdict is all-reduced
-            need = per_gpu * world * n_samples * 2 + (1 << 30)
-            fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0],
-                                dtype=torch.int32, device=dev)
-            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-            if int(fits.item()) == 0:
-                raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
-            g0 = time.perf_counter()
-            full_pcm = gather_pcm(local, per_gpu * world, dst=0)
-            sync_all()
-            g = time.perf_counter() - g0
-            nbytes = per_gpu * (world - 1) * n_samples * 2
-            gather = {"ms": round(g * 1e3, 3), "GB/s": round(nbytes / g / 1e9, 1),
-                      "bytes_into_rank0": nbytes, "included_in_value": False}
-            if rank == 0:
-                # every shard arrived where it belongs: rank r's first row is row r*per_gpu of the result
-                ok = bool(torch.equal(full_pcm[:1], local[:1]))
-                gather["rank0_block_intact"] = ok
-            del full_pcm
-        except Exception as exc:  # pragma: no cover - depends on the node's RCCL
-            gather = {"error": "%s: %s" % (type(exc).__name__, exc), "included_in_value": False}
 
     result = None
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            try:
-                rec = json.load(open(pmc_path)).get("config%d_%s_%d" % (args.config, args.arith, per_gpu))
-                if rec:
-                    traffic = rec["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        key = "config%d_%s_%d" % (args.config, args.arith, per_gpu)
+        rec = _profile_record("pmc_traffic.json", key)
+        traffic = rec["hbm_bytes_per_launch"] if rec else None
         tflops = FLOP_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e12
+        valu = None
+        sq = _profile_record("pmc_valu.json", key)
+        if sq:
+            # wave-instructions from the SQ counters of the committed profile of THIS kernel; the
+            # duration is this run's.  Issue ceiling of one wavefront per SIMD measured by
+            # tools/ubench: one fp64 instruction per 5.3 shader cycles.
+            wi = sq["SQ_INSTS_VALU_per_launch"]
+            per_sample = wi / (per_gpu * n_samples / 64.0)
+            rate = wi / (kern_ms_avg * 1e-3) / (4 * cus)            # wave-instructions per second per SIMD
+            valu = {"valu_wave_instructions_per_sample": round(per_sample, 2),
+                    "all_wave_instructions_per_sample": round(sq.get("SQ_INSTS_per_launch", 0) / (per_gpu * n_samples / 64.0), 2),
+                    "valu_issue_rate_per_simd_MHz": round(rate / 1e6, 1),
+                    "frac_of_one_wave_issue_ceiling": round(rate / (sq.get("clock_GHz", 2.3) * 1e9 / 5.3), 3),
+                    "source": "profiles/pmc_valu.json[%s]" % key}
         result = {
             "metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref",
             "value": round(value, 1),
@@ -275,20 +310,25 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "kernel": "vs_synth_kernel<%d, 0, false>" % arith,
+                "kernel": kernel_name,
                 "kernel_ms_avg": round(kern_ms_avg, 4),
+                "kernel_ms_min": round(min(kern_ms), 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples,
                 "fp64_valu": {"achieved_TFLOPs": round(tflops, 2), "peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
                               "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
                               "flop_per_sample": FLOP_PER_SAMPLE},
+                "valu": valu,
             },
             "other_arith": {"arith": "fma" if arith == vs.VS_ARITH_EXACT else "exact",
+                            "kernel": other_kernel,
                             "kernel_ms_avg": round(other_ms, 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
+            "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
+                     "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
+                             "sort, cos rows; allocation + upload + wait.  Outside every timed region."},
+            "launch_health_word": health,
             "device": dev_name.strip(),
         }
-        if gather:
-            result["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples,
                               args.cpu_seconds, first_rows)
@@ -298,7 +338,94 @@ def main():
                                       "normalised": cb.get("gpu_rms_error_normalised"),
                                       "rows_checked": cb.get("gpu_rows_checked"),
                                       "tolerance_normalised": 1e-5}
-        print(json.dumps(result), flush=True)
+
+    # ---- N > 1: synthesis WITH delivery of the PCM to rank 0 over RCCL, end to end ----
+    # Runs LAST and under a watchdog: should the exchange ever stall (it cannot be rehearsed with
+    # more than one rank on a one-GPU box), every rank leaves after GATHER_DEADLINE_S and rank 0
+    # still prints the line, with the stall reported instead of the gather figures.
+    gather = None
+    value_with_gather = None
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            if value_with_gather is not None:
+                result["value_with_gather"] = round(value_with_gather, 1)
+            if gather:
+                result["gather"] = gather
+            print(json.dumps(result), flush=True)
+
+    def watchdog():
+        if not leg_done.wait(GATHER_DEADLINE_S):
+            if rank == 0 and not printed.is_set():
+                printed.set()
+                result["gather"] = {"error": "no completion within %d s" % GATHER_DEADLINE_S, "included_in_value": False}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+    leg_done = threading.Event()
+    if world > 1 and not args.no_gather:
+        threading.Thread(target=watchdog, daemon=True).start()
+        # optional leg: it must never cost the benchmark line, so failures are reported
+        try:
+            # every rank must take the same decision, or the peers would wait for a root that
+            # gave up: rank 0 checks that the gathered PCM fits, the verdict is all-reduced
+            need = per_gpu * world * n_samples * 2 + (2 << 30)
+            fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0],
+                                dtype=torch.int32, device=dev)
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+            if int(fits.item()) == 0:
+                raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
+            del out
+            torch.cuda.empty_cache()
+            # chunk plans of this rank (host work, outside the timed part)
+            pg = PipelinedGather(per_gpu * world, n_samples, GATHER_CHUNK, dev)
+            plans = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), n_samples)
+                     for a_, b_ in pg.edges]
+
+            def launch_chunk(kk, tensor):
+                plans[kk].launch(vs.VS_KIND_SYNTH, tensor.data_ptr(), out_pitch=n_samples)
+
+            pg.run(launch_chunk)          # warm-up pass (RCCL connections, code objects)
+            sync_all()
+            g0 = time.perf_counter()
+            full_pcm = pg.run(launch_chunk)
+            sync_all()
+            g = time.perf_counter() - g0
+            gt = torch.tensor([g], dtype=torch.float64, device=dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            g = float(gt.item())
+            for p_ in plans:
+                p_.status()
+            nbytes = per_gpu * (world - 1) * n_samples * 2
+            value_with_gather = samples_per_step / g / 1e6
+            gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
+                      "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
+                      "ingress_GB/s": round(nbytes / g / 1e9, 1), "included_in_value": False,
+                      "transport": "RCCL send/recv, one grouped receive per chunk on the root (torch.distributed)"}
+            # the un-overlapped comparison: the same chunks, then one gather behind them
+            sync_all()
+            g0 = time.perf_counter()
+            for kk, tns in enumerate(pg.chunks):
+                launch_chunk(kk, tns)
+            torch.cuda.synchronize(dev)
+            again = gather_pcm(pg.base, per_gpu * world, dst=0)
+            sync_all()
+            g2 = time.perf_counter() - g0
+            gt = torch.tensor([g2], dtype=torch.float64, device=dev)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            gather["ms_compute_then_gather"] = round(float(gt.item()) * 1e3, 3)
+            if rank == 0:
+                gather["equals_unoverlapped_gather"] = bool(torch.equal(again, full_pcm))
+            del again, full_pcm
+            for p_ in plans:
+                p_.close()
+        except Exception as exc:  # pragma: no cover - depends on the node's RCCL
+            gather = {"error": "%s: %s" % (type(exc).__name__, exc), "included_in_value": False}
+
+    leg_done.set()
+    emit()
 
     plan.close()
     eng.close()

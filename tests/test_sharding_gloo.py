@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import voice_synth_amd as vs
 from voice_synth_amd import configs
-from voice_synth_amd.dist import gather_pcm, shard_range
+from voice_synth_amd.dist import PipelinedGather, gather_pcm, shard_range
 from oracle import pyoracle as po
 
 N_LANES = 11  # odd on purpose: ragged shards
@@ -45,6 +45,42 @@ def _worker(rank, world, port, out_path):
             assert full is None
     finally:
         dist.destroy_process_group()
+
+
+def _worker_pipelined(rank, world, port, out_path, n_lanes, chunk_rows):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        specs, fs, dur, _ = configs.config_specs(3, n_lanes)
+        lanes_all, d = vs.lanes_from_specs(specs)
+        n = 1500
+        pg = PipelinedGather(n_lanes, n, chunk_rows, "cpu")
+
+        def launch(k, tensor):           # the CPU oracle stands in for the device
+            a, b = pg.edges[k]
+            rows = po.synth([lanes_all[pg.lo + i] for i in range(a, b)], n, threads=1)
+            tensor.copy_(torch.from_numpy(rows))
+
+        dist.barrier()
+        full = pg.run(launch)
+        if rank == 0:
+            np.save(out_path, full.numpy())
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_three_ranks_ragged_chunks(tmp_path):
+    """chunk k of every rank travels to the root while chunk k+1 is produced; ranks differ in their
+    number of chunks (13 lanes over 3 ranks = 5 + 4 + 4, chunks of 2)"""
+    out = str(tmp_path / "pipelined.npy")
+    mp.spawn(_worker_pipelined, args=(3, _free_port(), out, 13, 2), nprocs=3, join=True)
+    got = np.load(out)
+    specs, fs, dur, _ = configs.config_specs(3, 13)
+    lanes, d = vs.lanes_from_specs(specs)
+    assert np.array_equal(got, po.synth(lanes, 1500, threads=2))
 
 
 def test_shard_range_partitions_exactly():

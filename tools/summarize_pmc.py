@@ -1,10 +1,16 @@
-"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as
-/opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes) of `bench.py --no-cpu-baseline`
-into profiles/pmc_traffic.json, which bench.py reads for roofline.traffic.
+"""Turns rocprofv3 --pmc passes of `bench.py --no-cpu-baseline` into the two small JSON files
+bench.py reads:
 
-Corrections applied (same guide): counters are in KiB (x1024); on gfx950 FETCH_SIZE reports
-half of the bytes of a read stream -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores,
-which is what the filter super-step issues."""
+  profiles/pmc_traffic.json  (roofline.traffic)  from two SEPARATE passes, FETCH_SIZE and
+      WRITE_SIZE, as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes.  Corrections
+      applied (same guide): counters are in KiB (x1024); on gfx950 FETCH_SIZE reports half of the
+      bytes of a read stream -> doubled; WRITE_SIZE is exact for 16-byte-per-lane stores, which is
+      what the filter super-step issues.
+  profiles/pmc_valu.json     (roofline.valu)     from one or two SQ passes: wave-instructions
+      by class, active / wait quad-cycles, per launch of the dominant kernel.
+
+usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <key> [kernel substring]
+       summarize_pmc.py valu <sq1.csv> [<sq2.csv> ...] <key> [--kernel substring]"""
 import csv
 import json
 import os
@@ -13,35 +19,76 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def per_kernel(path, counter):
-    vals = {}
+def per_kernel(path):
+    """{kernel: {counter: [values per dispatch]}} and {kernel: [durations ns]}"""
+    vals, dur = {}, {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    return vals
+        k = r["Kernel_Name"]
+        vals.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        try:
+            dur.setdefault(k, {})[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        except (KeyError, ValueError):
+            pass
+    return vals, dur
+
+
+def pick(vals, counter, want):
+    ks = [k for k in vals if counter in vals[k] and (want in k if want else k.startswith("void vs_synth"))]
+    ks.sort(key=lambda k: -len(vals[k][counter]))
+    return ks[0]
 
 
 def main():
-    fetch_csv, write_csv, key = sys.argv[1], sys.argv[2], sys.argv[3]
-    out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    data = json.load(open(out_path)) if os.path.exists(out_path) else {}
-    f = per_kernel(fetch_csv, "FETCH_SIZE")
-    w = per_kernel(write_csv, "WRITE_SIZE")
-    kern = [k for k in w if "vs_synth_kernel<0, 0" in k or "vs_synth_kernel<1, 0" in k]
-    kern.sort(key=lambda k: -len(w[k]))
-    k = kern[0]
-    fetch = sum(f[k]) / len(f[k]) * 1024 * 2
-    write = sum(w[k]) / len(w[k]) * 1024
-    data[key] = {
-        "kernel": k,
-        "launches_averaged": len(w[k]),
-        "FETCH_SIZE_KiB_raw": sum(f[k]) / len(f[k]),
-        "WRITE_SIZE_KiB_raw": sum(w[k]) / len(w[k]),
-        "fetch_bytes_corrected_x2": fetch,
-        "write_bytes": write,
-        "hbm_bytes_per_launch": fetch + write,
-    }
+    mode = sys.argv[1]
+    if mode == "traffic":
+        fetch_csv, write_csv, key = sys.argv[2], sys.argv[3], sys.argv[4]
+        want = sys.argv[5] if len(sys.argv) > 5 else ""
+        out_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+        f, _ = per_kernel(fetch_csv)
+        w, _ = per_kernel(write_csv)
+        k = pick(w, "WRITE_SIZE", want)
+        fv, wv = f[k]["FETCH_SIZE"], w[k]["WRITE_SIZE"]
+        fetch = sum(fv) / len(fv) * 1024 * 2
+        write = sum(wv) / len(wv) * 1024
+        data[key] = {
+            "kernel": k,
+            "launches_averaged": len(wv),
+            "FETCH_SIZE_KiB_raw": sum(fv) / len(fv),
+            "WRITE_SIZE_KiB_raw": sum(wv) / len(wv),
+            "fetch_bytes_corrected_x2": fetch,
+            "write_bytes": write,
+            "hbm_bytes_per_launch": fetch + write,
+        }
+    elif mode == "valu":
+        args = sys.argv[2:]
+        want = ""
+        if "--kernel" in args:
+            i = args.index("--kernel")
+            want = args[i + 1]
+            del args[i:i + 2]
+        csvs, key = args[:-1], args[-1]
+        out_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+        rec = {}
+        for path in csvs:
+            v, d = per_kernel(path)
+            cands = [x for x in v if (want in x if want else x.startswith("void vs_synth"))]
+            cands.sort(key=lambda x: -max(len(c) for c in v[x].values()))
+            k = cands[0]
+            rec["kernel"] = k
+            for counter, xs in v[k].items():
+                rec[counter + "_per_launch"] = sum(xs) / len(xs)
+            if k in d and d[k]:
+                ds = sorted(d[k].values())
+                rec["kernel_ns_under_profiler_median"] = ds[len(ds) // 2]
+            rec["launches_averaged"] = len(next(iter(v[k].values())))
+        # the guide: SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles
+        if "SQ_BUSY_CYCLES_per_launch" in rec and "kernel_ns_under_profiler_median" in rec:
+            pass
+        data[key] = rec
+    else:
+        sys.exit(__doc__)
     json.dump(data, open(out_path, "w"), indent=1)
     print(key, json.dumps(data[key]))
 

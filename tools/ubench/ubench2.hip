@@ -23,6 +23,8 @@
     unsigned u0 = threadIdx.x * 2654435761u + 7u, u1 = u0 ^ 0x9E3779B9u, u2 = u1 * 3u, u3 = u2 + 11u; \
     unsigned w0 = u0 + 1u, w1 = u1 + 2u, w2 = u2 + 3u, w3 = u3 + 4u;                       \
     unsigned long long q0 = u0, q1 = u1;                                                   \
+    float g0 = threadIdx.x * 0.5f + 1.0f, g1 = g0 + 1.5f, g2 = g0 + 2.5f, g3 = g0 + 3.5f;  \
+    float h0 = 0.999999f, h1 = 1.000001f;                                                  \
     unsigned la = (threadIdx.x & 63u) * 2u;                                                \
     lds[threadIdx.x] = (short)u0;                                                          \
     __syncthreads();                                                                       \
@@ -33,7 +35,7 @@
     }                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory"); \
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0; \
-    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3 + b0 + b1 + u0 + u1 + u2 + u3 + w0 + w1 + w2 + w3 + (double)q0 + (double)q1 + lds[threadIdx.x] + la; \
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + c0 + c1 + c2 + c3 + b0 + b1 + u0 + u1 + u2 + u3 + w0 + w1 + w2 + w3 + (double)q0 + (double)q1 + lds[threadIdx.x] + la + g0 + g1 + g2 + g3 + h0 + h1; \
   }
 
 // ---- 64 instructions per iteration unless noted ----
@@ -46,6 +48,11 @@ BENCH(k_muladd_chain2, REP16(asm volatile("v_mul_f64 %1, %4, %6\n\tv_mul_f64 %3,
 // fma chain (FMA-mode filter shape, one partial sum)
 BENCH(k_fma_chain, REP64(asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a0) : "v"(b0), "v"(b1));))
 BENCH(k_fma_chain4, REP16(asm volatile("v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));))
+// single precision: what an fp32 filter mode would issue
+BENCH(k_fma32_indep, REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3) : "v"(h0), "v"(h1));))
+BENCH(k_fma32_chain2, REP32(asm volatile("v_fma_f32 %0, %2, %3, %0\n\tv_fma_f32 %1, %2, %3, %1" : "+v"(g0), "+v"(g1) : "v"(h0), "v"(h1));))
+BENCH(k_pkfma32_indep, REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n\tv_pk_fma_f32 %1, %1, %4, %5\n\tv_pk_fma_f32 %2, %2, %4, %5\n\tv_pk_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));))
+BENCH(k_pkfma32_chain2, REP32(asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n\tv_pk_fma_f32 %1, %2, %3, %1" : "+v"(a0), "+v"(a1) : "v"(b0), "v"(b1));))
 // 32-bit integer streams
 BENCH(k_xor_indep, REP16(asm volatile("v_xor_b32 %0, %0, %4\n\tv_xor_b32 %1, %1, %4\n\tv_xor_b32 %2, %2, %4\n\tv_xor_b32 %3, %3, %4" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(w0));))
 BENCH(k_mad64_indep, REP16(asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, 0\n\tv_mad_u64_u32 %1, vcc, %4, %3, 0\n\tv_mad_u64_u32 %0, vcc, %5, %3, 0\n\tv_mad_u64_u32 %1, vcc, %2, %4, 0" : "=&v"(q0), "=&v"(q1) : "v"(u0), "v"(u1), "v"(u2), "v"(u3) : "vcc");))
@@ -86,6 +93,10 @@ int main()
       {"two interleaved mul+add chains", k_muladd_chain2, 64},
       {"fma chain (1 accumulator)", k_fma_chain, 64},
       {"fma chains (4 accumulators)", k_fma_chain4, 64},
+      {"v_fma_f32 indep x4", k_fma32_indep, 64},
+      {"v_fma_f32 two chains", k_fma32_chain2, 64},
+      {"v_pk_fma_f32 indep x4 (2 fp32 fma each)", k_pkfma32_indep, 64},
+      {"v_pk_fma_f32 two chains", k_pkfma32_chain2, 64},
       {"v_xor_b32 indep x4", k_xor_indep, 64},
       {"v_mad_u64_u32 indep", k_mad64_indep, 64},
       {"v_mul_hi_u32 indep", k_mulhi_indep, 64},

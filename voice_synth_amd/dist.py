@@ -53,3 +53,79 @@ def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
     for q in dist.batch_isend_irecv(ops):
         q.wait()
     return out
+
+
+def chunk_edges(rows, chunk_rows):
+    """[(a, b), ...] covering [0, rows) in steps of chunk_rows"""
+    step = max(1, int(chunk_rows))
+    return [(a, min(rows, a + step)) for a in range(0, rows, step)]
+
+
+class PipelinedGather:
+    """Synthesis in chunks with the delivery to rank `dst` riding behind it: chunk k of every rank
+    travels to the root (RCCL send/recv over xGMI: one transfer per peer link, grouped on the
+    root, no ring) while chunk k+1 is being synthesised.
+
+    Every rank owns the contiguous lane block shard_range(n_lanes_total, rank, world) and cuts it
+    into chunks of chunk_rows utterances; the root synthesises its own chunks in place in the
+    gathered buffer.  run(launch) calls launch(k, tensor) for each local chunk, in order; on a
+    GPU the call must only ENQUEUE the work on the current stream.  Backend-agnostic: the CPU
+    tests drive it with gloo and a synchronous launch."""
+
+    def __init__(self, n_lanes_total, n_samples, chunk_rows, device, dtype=torch.int16, dst=0):
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.dst = dst
+        self.n_total, self.n_samples, self.chunk_rows = int(n_lanes_total), int(n_samples), int(chunk_rows)
+        self.lo, self.hi = shard_range(self.n_total, self.rank, self.world)
+        self.edges = chunk_edges(self.hi - self.lo, self.chunk_rows)
+        self.cuda = torch.device(device).type == "cuda"
+        if self.rank == dst:
+            self.full = torch.empty((self.n_total, self.n_samples), dtype=dtype, device=device)
+            base = self.full[self.lo:self.hi]
+        else:
+            self.full = None
+            base = torch.empty((self.hi - self.lo, self.n_samples), dtype=dtype, device=device)
+        self.base = base  # this rank's rows, contiguous: [hi - lo, n_samples]
+        self.chunks = [base[a:b] for a, b in self.edges]
+        self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
+
+    def run(self, launch):
+        """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done."""
+        work = []
+        peers = [r for r in range(self.world) if r != self.dst]
+        peer_edges = {}
+        for r in peers:
+            lo, hi = shard_range(self.n_total, r, self.world)
+            peer_edges[r] = [(lo + a, lo + b) for a, b in chunk_edges(hi - lo, self.chunk_rows)]
+        n_rounds = max([len(self.edges)] + [len(e) for e in peer_edges.values()]) if self.rank == self.dst else len(self.edges)
+        for k in range(n_rounds):
+            ev = None
+            if k < len(self.chunks):
+                launch(k, self.chunks[k])
+                if self.cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+            if self.world == 1:
+                continue
+            if self.rank != self.dst:
+                if self.cuda:
+                    with torch.cuda.stream(self.comm_stream):
+                        self.comm_stream.wait_event(ev)
+                        work.append(dist.isend(self.chunks[k], self.dst))
+                else:
+                    work.append(dist.isend(self.chunks[k], self.dst))
+            else:
+                ops = [dist.P2POp(dist.irecv, self.full[peer_edges[r][k][0]:peer_edges[r][k][1]], r)
+                       for r in peers if k < len(peer_edges[r])]
+                if ops:
+                    if self.cuda:
+                        with torch.cuda.stream(self.comm_stream):
+                            work += dist.batch_isend_irecv(ops)
+                    else:
+                        work += dist.batch_isend_irecv(ops)
+        for w in work:
+            w.wait()
+        if self.cuda:
+            self.comm_stream.synchronize()
+            torch.cuda.current_stream().synchronize()
+        return self.full
