@@ -274,12 +274,20 @@ def main():
             # duration is this run's.  Issue ceiling of one wavefront per SIMD measured by
             # tools/ubench: one fp64 instruction per 5.3 shader cycles.
             wi = sq["SQ_INSTS_VALU_per_launch"]
-            per_sample = wi / (per_gpu * n_samples / 64.0)
-            rate = wi / (kern_ms_avg * 1e-3) / (4 * cus)            # wave-instructions per second per SIMD
-            valu = {"valu_wave_instructions_per_sample": round(per_sample, 2),
-                    "all_wave_instructions_per_sample": round(sq.get("SQ_INSTS_per_launch", 0) / (per_gpu * n_samples / 64.0), 2),
+            units = per_gpu * n_samples / 64.0                       # 64-utterance groups x samples
+            all_wi = sum(sq.get(k_, 0.0) for k_ in ("SQ_INSTS_VALU_per_launch", "SQ_INSTS_SALU_per_launch",
+                                                    "SQ_INSTS_LDS_per_launch", "SQ_INSTS_VMEM_WR_per_launch"))
+            rate = wi / (kern_ms_avg * 1e-3) / (4 * cus)            # VALU wave-instructions per second per SIMD
+            waves_per_simd = sq.get("SQ_WAVES_per_launch", 4.0 * cus) / (4.0 * cus)
+            valu = {"valu_wave_instructions_per_sample": round(wi / units, 2),
+                    "all_wave_instructions_per_sample": round(all_wi / units, 2),
+                    "waves_per_simd": round(waves_per_simd, 2),
                     "valu_issue_rate_per_simd_MHz": round(rate / 1e6, 1),
-                    "frac_of_one_wave_issue_ceiling": round(rate / (sq.get("clock_GHz", 2.3) * 1e9 / 5.3), 3),
+                    # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles (MI355X_MICROARCH.md): the
+                    # share of the SIMDs' time in which a vector instruction is executing
+                    "valu_pipe_busy_frac": (round(sq["SQ_ACTIVE_INST_VALU_per_launch"] / (sq["SQ_WAVE_CYCLES_per_launch"] / waves_per_simd), 3)
+                                            if "SQ_ACTIVE_INST_VALU_per_launch" in sq and "SQ_WAVE_CYCLES_per_launch" in sq else None),
+                    "kernel_in_profile": sq.get("kernel"),
                     "source": "profiles/pmc_valu.json[%s]" % key}
         result = {
             "metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref",

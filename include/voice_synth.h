@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define VS_ORDER 22            /* filter order, reference vowel_new.c:172 */
+/* Filter order.  The reference runs Order = 22 for every table (vowel_new.c:172); MAX_ORDER 40
+ * (vowel_new.c:33) is only the bound of its arrays.  A VS_VOWEL_CUSTOM coefficient set has
+ * exactly 22 taps: lower orders are expressed by trailing zeros (acc - 0*y == acc, so the result
+ * equals the reference's loop run with the smaller Order); orders 23..40 are not supported. */
+#define VS_ORDER 22
 #define VS_NCOEF (VS_ORDER + 1)
 
 /* return codes */

@@ -25,11 +25,11 @@ timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IN
 rc=$?; [ $rc -ne 0 ] && { tail -5 $ROOT/gpurun_out/prof_sq1.log; exit $rc; }
 timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $ROOT/gpurun_out/prof_sq2 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_sq2.log 2>&1
 rc=$?; cd $ROOT; [ $rc -ne 0 ] && { tail -5 gpurun_out/prof_sq2.log; }
-python tools/summarize_pmc.py traffic gpurun_out/prof_FETCH_SIZE/bench_counter_collection.csv gpurun_out/prof_WRITE_SIZE/bench_counter_collection.csv config3_exact_65536 "vs_synth_kernel<0, 0"
-python tools/summarize_pmc.py traffic gpurun_out/prof_FETCH_SIZE/bench_counter_collection.csv gpurun_out/prof_WRITE_SIZE/bench_counter_collection.csv config3_fma_65536 "vs_synth_kernel<1, 0"
+python tools/summarize_pmc.py traffic gpurun_out/prof_FETCH_SIZE/bench_counter_collection.csv gpurun_out/prof_WRITE_SIZE/bench_counter_collection.csv config3_exact_65536 "vs_synth_ws_kernel<0"
+python tools/summarize_pmc.py traffic gpurun_out/prof_FETCH_SIZE/bench_counter_collection.csv gpurun_out/prof_WRITE_SIZE/bench_counter_collection.csv config3_fma_65536 "vs_synth_ws_kernel<1"
 SQ="gpurun_out/prof_sq1/bench_counter_collection.csv"; [ -f gpurun_out/prof_sq2/bench_counter_collection.csv ] && SQ="$SQ gpurun_out/prof_sq2/bench_counter_collection.csv"
-python tools/summarize_pmc.py valu $SQ config3_exact_65536 --kernel "vs_synth_kernel<0, 0"
-python tools/summarize_pmc.py valu $SQ config3_fma_65536 --kernel "vs_synth_kernel<1, 0"
+python tools/summarize_pmc.py valu $SQ config3_exact_65536 --kernel "vs_synth_ws_kernel<0"
+python tools/summarize_pmc.py valu $SQ config3_fma_65536 --kernel "vs_synth_ws_kernel<1"
 cp profiles/pmc_traffic.json profiles/pmc_valu.json gpurun_out/
 timeout -k 10 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
 rc=$?; cat gpurun_out/bench.json; tail -3 gpurun_out/bench.err

@@ -94,7 +94,7 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->kernel != VS_KERNEL_AUTO && t->kernel != VS_KERNEL_SINGLE && t->kernel != VS_KERNEL_WS) return VS_ERR_ARG;
   if (t->ring_slots < 0 || t->ring_slots > 65536) return VS_ERR_ARG;
   if (t->ready_min < 0 || t->ready_min > 64) return VS_ERR_ARG;
-  if (t->ws_pairs < 0 || t->ws_pairs > 2) return VS_ERR_ARG;
+  if (t->ws_pairs < 0 || t->ws_pairs == 3 || t->ws_pairs > 4) return VS_ERR_ARG;
   /* a lane short of gen_low samples starts a round at once: below one super-step the filter wave
    * could starve while the generator waits for company */
   if (t->gen_low != 0 && t->gen_low < VS_SS) return VS_ERR_ARG;
@@ -438,17 +438,22 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       });
     }
   }
-  /* Launch shape.  A full chip is 4 x cu_count wavefronts, one per SIMD.
-   *  - at least that many 64-utterance groups: one wavefront per group, ring sized so that four
-   *    workgroups share a CU's 160 KiB of LDS;
-   *  - at most half of that (e.g. BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU):
-   *    the WAVE-SPECIALISED kernel -- a generator wavefront and a filter wavefront per group, each
-   *    with a SIMD of its own (two pairs per 256-thread workgroup when that makes one workgroup
-   *    per CU); 1.35-1.45x faster than leaving half of the SIMDs idle. */
+  /* Launch shape.  A full chip is 4 x cu_count SIMDs.  The fused kind runs WAVE-SPECIALISED
+   * whenever it can: a generator wavefront and a filter wavefront per 64 utterances, coupled
+   * through the LDS ring (vs_synth_ws_kernel).
+   *  - up to half of the SIMDs' worth of groups (e.g. BASELINE config 4 sharded over 8 GPUs, 32768
+   *    utterances per GPU): every wavefront has a SIMD of its own and a launch takes
+   *    max(generator, filter) instead of their sum (1.35-1.45x);
+   *  - full grids (BASELINE config 3: 1024 groups on 1024 SIMDs): four pairs per 512-thread
+   *    workgroup, one workgroup per CU, laid out so that every SIMD hosts the generator and the
+   *    filter of one pair, the filter wavefront at raised priority.  One wavefront alone issues an
+   *    instruction every ~5.3 cycles; two on a SIMD fill each other's gaps (measured: 13 % faster
+   *    than one wavefront doing both jobs, profiles/r02_ws_full_grid_sweep.txt).
+   * The one-wave kernel remains for the source-only and filter-only kinds, the per-cycle log, the
+   * vowel -n power sums, and rings too long for a pair to fit the LDS. */
   const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
   const unsigned grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
-  const unsigned simds = 4u * cus;
-  int wave_specialised = (2u * grid <= simds);
+  int wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_WS) wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
   if (filter_only) wave_specialised = 0;
@@ -465,10 +470,12 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (!filter_only) {
     int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
     if (rc != VS_OK) return rc;
-    /* measured on 16384 / 32768 utterances (tools/gpu_sweep.sh): with a SIMD per wavefront the
+    /* measured (tools/gpu_sweep.sh, tools/gpu_r2_probe4.sh): with a SIMD per wavefront the
      * generator has slack, so it should feed the filter eagerly (rounds from 25 % attendance) and
-     * the filter should not wait for stragglers (super-steps from 62 %); ring size is immaterial */
-    if (wave_specialised) ready_min = 40;
+     * the filter should not wait for stragglers (super-steps from 62 %); when generator and
+     * filter share a SIMD the filter is the bottleneck and only runs full super-steps */
+    const bool ws_shared_simd = wave_specialised && grid > 2u * cus;
+    if (wave_specialised) ready_min = ws_shared_simd ? 64 : 40;
     if (tune.ready_min > 0) ready_min = tune.ready_min;
     /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
      * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
@@ -493,9 +500,9 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     ws_pair_bytes = (int)((lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
     if (wave_specialised) {
       if ((size_t)ws_pair_bytes > VS_LDS_LIMIT) wave_specialised = 0;
-      ws_pairs = (grid > cus && grid <= 2u * cus) ? 2 : 1;
+      ws_pairs = (grid <= cus) ? 1 : (grid <= 2u * cus ? 2 : 4);
       if (tune.ws_pairs > 0) ws_pairs = tune.ws_pairs;
-      if (2 * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs = 1;
+      while (ws_pairs > 1 && (size_t)ws_pairs * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs >>= 1;
     }
   }
 
@@ -654,10 +661,11 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;
   a.ws_pair_bytes = p->ws_pair_bytes;
-  a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : 16;
+  a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : (p->ws_pairs == 4 ? 32 : 16);
   a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : 2 * VS_SS;
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;
+  a.ws_filter_prio = 3;
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);

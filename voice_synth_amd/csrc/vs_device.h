@@ -73,6 +73,7 @@ typedef struct VsKernelArgs {
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   int spin_limit;     /* polls before a waiting wave gives up and sets err */
   int fault;          /* VS_FAULT_* (tests only) */
+  int ws_filter_prio; /* wave-specialised kernel: s_setprio of the filter wave (0 = leave at 0) */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
 } VsKernelArgs;
 

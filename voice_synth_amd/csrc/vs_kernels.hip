@@ -1085,15 +1085,21 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 #endif
 
 template <int ARITH, bool PRE1>
-__global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArgs args)
+__global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
 
-  /* a workgroup holds ws_pairs generator/filter pairs (blockDim = 128 * ws_pairs): with two
-   * pairs (256 threads) and one workgroup per CU the four wavefronts land on the CU's four
-   * SIMDs, which two separate 128-thread workgroups are not guaranteed to do */
-  const int pair = (int)threadIdx.x >> 7;
-  const int wave = ((int)threadIdx.x >> 6) & 1;
+  /* A workgroup holds ws_pairs generator/filter pairs (blockDim = 128 * ws_pairs).  Its
+   * wavefronts are laid out ROLE-MAJOR -- all generators first, then all filters -- because a
+   * workgroup's wavefronts are dealt to the CU's four SIMDs cyclically:
+   *   2 pairs (256 threads, half-filled chip): four wavefronts on four SIMDs, one each;
+   *   4 pairs (512 threads, one workgroup per CU, full chip): wavefront w and w+4 share a SIMD,
+   *     i.e. every SIMD hosts the generator AND the filter of the same pair -- never two filters
+   *     (which would halve the longer stream's issue rate) and never two generators. */
+  const int npairs = (int)blockDim.x >> 7;
+  const int widx = (int)threadIdx.x >> 6;
+  const int wave = widx / npairs; /* 0: generator, 1: filter */
+  const int pair = widx - wave * npairs;
   const int lane = (int)threadIdx.x & (VS_WAVE - 1);
   const long group = (long)blockIdx.x * (long)(blockDim.x >> 7) + pair;
   const long gl = group * VS_WAVE + lane;
@@ -1160,6 +1166,11 @@ __global__ void __launch_bounds__(4 * VS_WAVE, 1) vs_synth_ws_kernel(VsKernelArg
     if (args.ncyc && valid) args.ncyc[row] = s.cyc;
   } else {
     /* --------------------------------- filter wave --------------------------------- */
+    /* When a generator and a filter wave share a SIMD (full grids), VALU issue goes to the
+     * higher priority first: the filter wave is the longer of the two instruction streams, so
+     * it issues as if it were alone and the generator fills the slots it leaves.  Without this
+     * the two alternate and the launch takes twice the filter's time. */
+    if (args.ws_filter_prio > 0) __builtin_amdgcn_s_setprio(3);
     double a[VS_ORDER + 1];
     double y[VS_SS];
     a[0] = 1.0;
