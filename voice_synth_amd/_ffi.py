@@ -117,7 +117,7 @@ class DevLane(C.Structure):
         ("okey0", C.c_uint32),
         ("okey1", C.c_uint32),
         ("thr", C.c_int32),
-        ("pad_", C.c_int32),
+        ("ready_min", C.c_int32),
     ]
 
 

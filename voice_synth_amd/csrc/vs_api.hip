@@ -470,13 +470,27 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (!filter_only) {
     int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
     if (rc != VS_OK) return rc;
-    /* measured (tools/gpu_sweep.sh, tools/gpu_r2_probe4.sh): with a SIMD per wavefront the
-     * generator has slack, so it should feed the filter eagerly (rounds from 25 % attendance) and
-     * the filter should not wait for stragglers (super-steps from 62 %); when generator and
-     * filter share a SIMD the filter is the bottleneck and only runs full super-steps */
+    /* Super-step threshold, per 64-utterance group, from how many of the group's longest cycles
+     * its ring holds (rho): a group whose ring holds barely one cycle cannot wait for all of its
+     * lanes.  One-wave kernel: the table of vs_ring_policy (replayed period sequences).
+     * Wave-specialised kernel, measured (tools/gpu_sweep.sh, gpu_r2_probe4.sh, gpu_r2_ab4.sh): with
+     * a SIMD per wavefront the generator has slack, so the filter should not wait for stragglers
+     * (super-steps from 62 %); when generator and filter share a SIMD the filter is the
+     * bottleneck and only runs full super-steps if the ring is deep enough (rho >= 1.65: BASELINE
+     * config 3), three quarters otherwise (the long periods of config 5's F0 sweep). */
     const bool ws_shared_simd = wave_specialised && grid > 2u * cus;
-    if (wave_specialised) ready_min = ws_shared_simd ? 64 : 40;
-    if (tune.ready_min > 0) ready_min = tune.ready_min;
+    for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
+      int tb = 1;
+      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) tb = std::max(tb, (int)dl[l].tbound);
+      const double rho = (double)(slots - VS_SS) / (double)tb;
+      int thr = 32;
+      if (rho >= 1.65) thr = 64;
+      else if (rho >= 1.45) thr = 58;
+      else if (rho >= 1.33) thr = 48;
+      if (wave_specialised) thr = ws_shared_simd ? (rho >= 1.65 ? 64 : 48) : 40;
+      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) dl[l].ready_min = thr;
+    }
+    ready_min = tune.ready_min > 0 ? tune.ready_min : 0; /* 0: the groups' own thresholds */
     /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
      * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
     for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {

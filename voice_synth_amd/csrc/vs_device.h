@@ -47,7 +47,7 @@ typedef struct VsDevLane {
   int32_t Lframe;     /* 50 * ((int)(fs*0.001/2.0)*2), the frame the noise power is taken over (vowel_new.c:361-363) */
   uint32_t okey0, okey1; /* Philox key of the vowel stage's draw stream */
   int32_t thr;        /* ceil(par.DC) as an integer: for an integer x, (float)x < par.DC  <=>  x < thr   (fg:320, 329) */
-  int32_t pad_;
+  int32_t ready_min;  /* super-step threshold of this lane's 64-utterance group (the same in all its lanes): ready lanes * 64 >= live lanes * ready_min */
 } VsDevLane;
 
 typedef struct VsKernelArgs {
@@ -63,7 +63,7 @@ typedef struct VsKernelArgs {
   int ring_slots;
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
-  int ready_min;      /* super-step threshold: ready lanes * 64 >= live lanes * ready_min */
+  int ready_min;      /* > 0: super-step threshold for every group (vs_tuning); 0: each group's own VsDevLane.ready_min */
   int ws_pairs;       /* wave-specialised kernel: generator/filter pairs per workgroup (1 or 2) */
   int ws_pair_bytes;  /* LDS bytes of one pair: ring + trash row + cos rows + progress words, 16-byte multiple */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */

@@ -346,6 +346,10 @@ __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDia
  * square is exact in 32-bit integers and its conversion rounds exactly as the float product. */
 __device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
 
+#ifndef VS_PUB_EVERY
+#define VS_PUB_EVERY 1 /* wave-specialised kernel: the generator publishes its noise progress every N-th trip (power of two) */
+#endif
+
 /* Largest noise width the short noise sequence takes (see vs_noise_fast()). */
 #define VS_NDW_FAST 65534
 
@@ -665,6 +669,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
                              __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      int trip = 0;
       while (__any(q0 < m)) {
         uint32_t o[8];
         vs_philox2(b, rk, o);
@@ -675,7 +680,8 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         vs_run8_store_all(r8, xv);
         q0 += 8;
         b += 2u;
-        if (PUB) {
+        ++trip;
+        if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
           const int done = (q0 < m) ? q0 : m;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __hip_atomic_store(gpub_lane, s.g + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -950,6 +956,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   const double gain = L->gain;
   const double pre = L->pre;
   const long row = (long)L->row;
+  /* the group's super-step threshold (the same in all its lanes), unless the launch sets one */
+  const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
 
   VsCfg c;
   VsGen s;
@@ -1001,7 +1009,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
       const bool want = live && s.pend && (s.g - n + s.T + VS_TRASH_ROWS <= C);
       const int n_live = __builtin_popcountll(__ballot(live));
       const int n_ready = __builtin_popcountll(__ballot(ready));
-      const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * args.ready_min) || !__any(want));
+      const bool filter_now = (n_ready > 0) && ((n_ready * 64 >= n_live * ready_min) || !__any(want));
       if (!filter_now) {
         if (want) {
           vs_cycle_emit<LOG>(c, s, ring, C, lane, N, ltab, logrow, (int)args.log_pitch, dg);
@@ -1081,7 +1089,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  * the launch is set and the wave leaves) so that a protocol bug cannot hang the device.
  */
 #ifndef VS_POLL_SLEEP
-#define VS_POLL_SLEEP 8 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one */
+#define VS_POLL_SLEEP 32 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one (A/B: 1, 2, 8, 32 -- 32 best by ~2 %) */
 #endif
 
 template <int ARITH, bool PRE1>
@@ -1181,6 +1189,7 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
     const double gain = L->gain;
     const double pre = L->pre;
     int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+    const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
     int n = 0, rslot = 0, spins = 0;
     bool live = valid;
 #ifdef VS_DIAG
@@ -1196,7 +1205,7 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
       const bool ready = live && ((g_seen - n >= VS_SS) || (g_seen >= N));
       const int n_live = __builtin_popcountll(__ballot(live));
       const int n_ready = __builtin_popcountll(__ballot(ready));
-      if ((n_ready > 0) && (n_ready * 64 >= n_live * args.ready_min)) {
+      if ((n_ready > 0) && (n_ready * 64 >= n_live * ready_min)) {
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
