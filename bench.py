@@ -379,7 +379,7 @@ def main():
         try:
             # every rank must take the same decision, or the peers would wait for a root that
             # gave up: rank 0 checks that the gathered PCM fits, the verdict is all-reduced
-            need = per_gpu * world * n_samples * 2 + (2 << 30)
+            need = 2 * per_gpu * world * n_samples * 2 + (2 << 30)   # the gathered PCM, twice (overlapped + comparison)
             fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0],
                                 dtype=torch.int32, device=dev)
             dist.all_reduce(fits, op=dist.ReduceOp.MIN)

@@ -175,7 +175,7 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
  * measurements (tools/) and tests.  Values are validated here, once, and copied into every plan
  * made afterwards; nothing else can change what a plan launches -- in particular no environment
  * variable does, unless VS_DEBUG_TUNING=1 asks vs_ctx_create() to read the experiment knobs
- * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_GEN_LOW, VS_GEN_MIN) through this
+ * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_GEN_LOW, VS_GEN_MIN, VS_WS_PRIO) through this
  * same function.  NULL resets. */
 #define VS_KERNEL_AUTO 0
 #define VS_KERNEL_SINGLE 1 /* one wavefront per 64 utterances generates and filters */
@@ -185,11 +185,12 @@ typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
   int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */
   int32_t ready_min;  /* 1..64: a super-step runs when ready lanes * 64 >= live lanes * ready_min */
-  int32_t ws_pairs;   /* 1 or 2 generator/filter pairs per workgroup (2 only if both fit the LDS) */
+  int32_t ws_pairs;   /* 1, 2 or 4 generator/filter pairs per workgroup (as many as fit the LDS) */
   int32_t gen_low;    /* >= 24: a lane with fewer buffered samples starts a generator round at once */
   int32_t gen_min;    /* 1..64: a round starts when wanting lanes * 64 >= needing lanes * gen_min */
   int32_t spin_limit; /* polls before a waiting wavefront gives up with VS_ERR_INTERNAL */
   int32_t fault;      /* VS_FAULT_* */
+  int32_t ws_filter_prio; /* s_setprio of the filter wavefront: 0 = default (3), 1..3, -1 = leave it at 0 */
 } vs_tuning;
 int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
 /* Device self-test of the arithmetic shortcuts the kernels take: [0] division shortcut

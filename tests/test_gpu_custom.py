@@ -82,6 +82,23 @@ def test_config5_blended_pole_sets_full_batch_sampled(engine):
     assert np.array_equal(pcm[pick], po.synth([lanes[i] for i in pick], ns))
 
 
+@pytest.mark.parametrize("pairs", [1, 2, 4])
+def test_every_workgroup_shape_of_the_ws_kernel_on_ragged_batches(pairs):
+    """1, 2 and 4 generator/filter pairs per workgroup (role-major layout), on batches that leave
+    pairs of the last workgroup partly or wholly without utterances"""
+    eng = vs.Engine(0)
+    eng.set_tuning(kernel=vs.VS_KERNEL_WS, ws_pairs=pairs)
+    try:
+        for index, n in ((3, 130), (5, 321), (2, 64), (3, 1)):
+            specs, fs, dur, _ = configs.config_specs(index, n)
+            lanes, d = vs.lanes_from_specs(specs)
+            ns = 5000
+            got = eng.synth(lanes, ns)
+            assert np.array_equal(got, po.synth(lanes, ns)), (pairs, index, n)
+    finally:
+        eng.close()
+
+
 def test_config2_at_its_real_batch(engine):
     """BASELINE config 2 at its own size: 1024 utterances = 16 groups, the wave-specialised kernel"""
     specs, fs, dur, _ = configs.config_specs(2, 1024)

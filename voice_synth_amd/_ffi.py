@@ -133,6 +133,7 @@ class Tuning(C.Structure):
         ("gen_min", C.c_int32),
         ("spin_limit", C.c_int32),
         ("fault", C.c_int32),
+        ("ws_filter_prio", C.c_int32),
     ]
 
 

@@ -74,6 +74,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
       if ((v = getenv("VS_WS_PAIRS")) != nullptr) t.ws_pairs = atoi(v);
       if ((v = getenv("VS_GEN_LOW")) != nullptr) t.gen_low = atoi(v);
       if ((v = getenv("VS_GEN_MIN")) != nullptr) t.gen_min = atoi(v);
+      if ((v = getenv("VS_WS_PRIO")) != nullptr) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
       if (vs_ctx_set_tuning(ctx, &t) != VS_OK) {
         delete ctx;
         return VS_ERR_ARG;
@@ -101,6 +102,7 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->gen_min < 0 || t->gen_min > 64) return VS_ERR_ARG;
   if (t->spin_limit < 0) return VS_ERR_ARG;
   if (t->fault != 0 && t->fault != VS_FAULT_WITHHOLD_PROGRESS) return VS_ERR_ARG;
+  if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   ctx->tuning = *t;
   return VS_OK;
 }
@@ -679,7 +681,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : 2 * VS_SS;
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;
-  a.ws_filter_prio = 3;
+  a.ws_filter_prio = p->tuning.ws_filter_prio == 0 ? 3 : (p->tuning.ws_filter_prio < 0 ? 0 : p->tuning.ws_filter_prio);
   /* 16-byte vector stores need every row start 4-byte aligned */
   int vec = ((out_pitch & 1) == 0) && ((((uintptr_t)out_dev) & 3) == 0);
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);

@@ -1178,7 +1178,9 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
      * higher priority first: the filter wave is the longer of the two instruction streams, so
      * it issues as if it were alone and the generator fills the slots it leaves.  Without this
      * the two alternate and the launch takes twice the filter's time. */
-    if (args.ws_filter_prio > 0) __builtin_amdgcn_s_setprio(3);
+    if (args.ws_filter_prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (args.ws_filter_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (args.ws_filter_prio == 1) __builtin_amdgcn_s_setprio(1);
     double a[VS_ORDER + 1];
     double y[VS_SS];
     a[0] = 1.0;
