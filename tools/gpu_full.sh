@@ -21,7 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d $ROOT/gpurun_out/prof_$C -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_$C.log 2>&1
 rc=$?; [ $rc -ne 0 ] && { tail -5 $ROOT/gpurun_out/prof_$C.log; exit $rc; }
 done
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $ROOT/gpurun_out/prof_sq1 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_sq1.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $ROOT/gpurun_out/prof_sq1 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_sq1.log 2>&1
 rc=$?; [ $rc -ne 0 ] && { tail -5 $ROOT/gpurun_out/prof_sq1.log; exit $rc; }
 timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $ROOT/gpurun_out/prof_sq2 -o bench -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_sq2.log 2>&1
 rc=$?; cd $ROOT; [ $rc -ne 0 ] && { tail -5 gpurun_out/prof_sq2.log; }

@@ -83,9 +83,9 @@ def main():
                 ds = sorted(d[k].values())
                 rec["kernel_ns_under_profiler_median"] = ds[len(ds) // 2]
             rec["launches_averaged"] = len(next(iter(v[k].values())))
-        # the guide: SQ_WAVE_CYCLES / SQ_BUSY_CYCLES / SQ_ACTIVE_INST_* / SQ_WAIT_* count quad-cycles
-        if "SQ_BUSY_CYCLES_per_launch" in rec and "kernel_ns_under_profiler_median" in rec:
-            pass
+        # effective clock (MI355X_MICROARCH.md, DVFS): GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        if "GRBM_GUI_ACTIVE_per_launch" in rec and "kernel_ns_under_profiler_median" in rec:
+            rec["clock_GHz_under_profiler"] = rec["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / rec["kernel_ns_under_profiler_median"]
         data[key] = rec
     else:
         sys.exit(__doc__)

@@ -4,6 +4,7 @@
 // free in the shadow of an fp64 one; what do LDS byte accesses and exec-mask branches cost.
 // Build: hipcc -O3 --offload-arch=gfx950 -o ubench2 ubench2.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 
@@ -81,6 +82,24 @@ BENCH(k_ds_write_f64mix, REP16(asm volatile("ds_write_b16 %2, %3\n\tv_mul_f64 %0
 BENCH(k_salu_mix, REP16(asm volatile("v_mul_f64 %0, %0, %2\n\ts_add_u32 s20, s20, 1\n\tv_mul_f64 %1, %1, %2\n\ts_and_b32 s21, s20, 7" : "+v"(a0), "+v"(a1) : "v"(b0) : "s20", "s21");))
 BENCH(k_saveexec_mix, REP16(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_and_saveexec_b64 s[20:21], vcc\n\tv_add_u32 %0, %0, %2\n\ts_or_b64 exec, exec, s[20:21]" : "+v"(u0) : "v"(w0), "v"(w1) : "vcc", "s20", "s21");))
 
+// in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): delta s_memtime / delta s_memrealtime x 100 MHz
+__global__ void k_clock(unsigned long long *out, double *sink, int iters)
+{
+  double a0 = threadIdx.x * 1.0001 + 1.0, a1 = a0 + 1.5, a2 = a0 + 2.5, a3 = a0 + 3.5, b0 = 0.999999;
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+    REP16(asm volatile("v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %4\n\tv_mul_f64 %2, %2, %4\n\tv_mul_f64 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));)
+  }
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned wv = blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    out[2 * wv] = t1 - t0;
+    out[2 * wv + 1] = r1 - r0;
+  }
+  sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
 typedef void (*kern_t)(unsigned long long *, double *, int);
 struct Case { const char *name; kern_t fn; int instr_per_iter; };
 
@@ -131,9 +150,13 @@ int main()
   for (auto &c : cases) {
     printf("%-42s", c.name);
     for (int w : wps) {
-      const int grid = 1024 * w;  // 64-thread workgroups: w waves per SIMD on 256 CUs
-      hipLaunchKernelGGL(c.fn, dim3(grid), dim3(64), 0, 0, d_out, d_sink, iters);
-      hipLaunchKernelGGL(c.fn, dim3(grid), dim3(64), 0, 0, d_out, d_sink, iters);
+      // ONE workgroup of 4*w wavefronts per CU: a workgroup's wavefronts are dealt to the CU's four
+      // SIMDs cyclically, so every SIMD gets exactly w of them (single-wave workgroups land
+      // unevenly -- 3+3+1+1 instead of 2+2+2+2 -- which is what the first version of this
+      // benchmark measured without knowing it)
+      const int grid = 1024 * w;  // wavefronts
+      hipLaunchKernelGGL(c.fn, dim3(256), dim3(256 * w), 0, 0, d_out, d_sink, iters);
+      hipLaunchKernelGGL(c.fn, dim3(256), dim3(256 * w), 0, 0, d_out, d_sink, iters);
       hipDeviceSynchronize();
       hipMemcpy(h.data(), d_out, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       double s = 0;
@@ -150,10 +173,10 @@ int main()
   hipEventCreate(&e1);
   for (int w : wps) {
     const int grid = 1024 * w;
-    hipLaunchKernelGGL(k_f64_indep, dim3(grid), dim3(64), 0, 0, d_out, d_sink, 20000);
+    hipLaunchKernelGGL(k_f64_indep, dim3(256), dim3(256 * w), 0, 0, d_out, d_sink, 20000);
     hipDeviceSynchronize();
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_f64_indep, dim3(grid), dim3(64), 0, 0, d_out, d_sink, 20000);
+    hipLaunchKernelGGL(k_f64_indep, dim3(256), dim3(256 * w), 0, 0, d_out, d_sink, 20000);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms = 0;
@@ -164,6 +187,25 @@ int main()
     s /= grid;
     printf("wall check, %d wave(s)/SIMD: %.3f ms for %.0f ticks per wave -> %.3f GHz tick rate; %.2f TFLOP/s fp64 (mul only)\n",
            w, ms, s, s / (ms * 1e6), (double)grid * 64 * 20000 * 64 / (ms * 1e-3) / 1e12);
+  }
+  // the same question asked inside the kernel: shader cycles per 100 MHz reference tick
+  {
+    unsigned long long *d2;
+    hipMalloc(&d2, 2 * 4096 * sizeof(unsigned long long));
+    std::vector<unsigned long long> h2(2 * 4096);
+    for (int w : wps) {
+      const int grid = 1024 * w;
+      for (int rep = 0; rep < 40; ++rep)  // ~0.3-1 s of back-to-back launches: let the clock settle
+        hipLaunchKernelGGL(k_clock, dim3(256), dim3(256 * w), 0, 0, d2, d_sink, 20000);
+      hipDeviceSynchronize();
+      hipMemcpy(h2.data(), d2, 2 * grid * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      std::vector<double> ghz(grid);
+      for (int i = 0; i < grid; ++i) ghz[i] = (double)h2[2 * i] / (double)h2[2 * i + 1] * 0.1;
+      std::sort(ghz.begin(), ghz.end());
+      printf("in-kernel clock, %d wave(s)/SIMD of v_mul_f64: median %.3f GHz (min %.3f, max %.3f) = delta s_memtime / delta s_memrealtime x 100 MHz\n",
+             w, ghz[grid / 2], ghz[0], ghz[grid - 1]);
+    }
+    hipFree(d2);
   }
   hipFree(d_out);
   hipFree(d_sink);
