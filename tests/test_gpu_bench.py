@@ -23,6 +23,9 @@ def _check(line, steps):
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] > 0
+    assert d["launch_health_word"] == 0                     # vs_plan_status after the timed launches
+    assert d["plan"]["host_ms"] >= 0 and d["plan"]["upload_ms"] >= 0
     return d
 
 
@@ -33,6 +36,9 @@ def test_bench_single_process_small():
     d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["cpu_baseline"]["gpu_rows_checked"] >= 1 and d["cpu_baseline"]["gpu_mismatched_samples"] == 0
+    ref = d["cpu_baseline"].get("reference_as_shipped")
+    if ref:                                                  # oracle/_ref travels to the GPU box
+        assert ref["O0_as_shipped"]["matches_port"] and ref["O2"]["matches_port"]
 
 
 def _free_port():
