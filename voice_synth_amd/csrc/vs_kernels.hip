@@ -354,35 +354,38 @@ __device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
 #define VS_NDW_FAST 65534
 
 /*
- * w[i] = (signed short)ceil(((1.0*random())/RAND_MAX)*NoiseDistWidth - NoiseDistWidth/2.)
- * (flowgen_shimmer.c:387, 398) for a draw r in [0, 2^31) and a width N <= VS_NDW_FAST, as
- *     Kn - trunc(fma(r, -N*inv, Kn + N/2)),     Kn = (N >> 1) + 1,  inv = 0x1.00000002p-31
+ * One noise sample of the closed phase (flowgen_shimmer.c:387-389, 398-400):
+ *     w    = (signed short)ceil(((1.0*random())/RAND_MAX)*NoiseDistWidth - NoiseDistWidth/2.)
+ *     x[i] = truncate((float)x[i] + w)            with x[i] = (short)par.DC on [T3, T)
+ * for a draw r in [0, 2^31), a width N <= VS_NDW_FAST and |(short)DC| + N/2 + 2 <= 32767 (no clamp,
+ * no wrap), as the LOW 16 BITS of
+ *     trunc(fma(r, N*inv, I - N/2 + 1 - 1e-10)),      I = (short)DC + 65536,  inv = 0x1.00000002p-31
+ * -- one conversion, one fused multiply-add, one conversion, and the store takes the low half.
  * Why this is the reference's value for every r: with M = 2^31 - 1 (a prime) the exact quantity
  * V = r*N/M - N/2 is an integer only for r = 0 and r = M; for every other r it lies at least
- * 1/(2M) = 2.3e-10 from an integer.  The reference's three roundings (quotient, product,
- * difference) and the single rounding here (N*inv is exact for N < 2^21; r*N*inv = r*N/M *
- * (1 - 2^-62)) each stay within N * 2^-52 < 1.5e-11 of V, so both round to the same side of
- * every integer; at r = 0 and r = M both are exact (-N/2 and N/2).  Kn - V > 0, so truncation
- * is the floor, and ceil(V) = Kn - floor(Kn - V).  |w| <= N/2 < 32768: the short cast is the
- * identity.  Checked exhaustively over r for a set of N, and over all N at the edge draws, by
- * tests/test_noise_shortcut.py (CPU) and by vs_ctx_selftest() on the device.
+ * 1/(2M) = 2.3e-10 from an integer.  ceil(V) = floor(V + 1 - d) for any 0 < d <= 2.3e-10 then (and
+ * for integer V), and adding the integer I makes the argument positive, so truncation is the
+ * floor.  The reference's three roundings (quotient, product, difference) stay within N*2^-52 <
+ * 1.5e-11 of V; here N*inv is exact (N < 2^21), r*N*inv = r*N/M*(1 - 2^-62), the constant and the
+ * fma round once each at magnitude < 2^18 (<= 1.5e-11 each): 2.2e-11 in all, against margins of
+ * 1e-10 below and 1.3e-10 above the integer boundaries.  Adding 65536 does not change the low 16
+ * bits.  Checked exhaustively over r for a set of N (and DC values), and over all N at the edge
+ * draws, by tests/test_noise_shortcut.py (CPU) and by vs_ctx_selftest() on the device.
  */
 struct VsNoiseK {
-  double negc, kh;
-  int xbase; /* (short)DC + Kn: the sample is xbase - trunc(...) */
+  double c, k2;
 };
 __device__ __forceinline__ VsNoiseK vs_noise_consts(int NDW, int dcs)
 {
   VsNoiseK k;
-  const int Kn = (NDW >> 1) + 1;
-  k.negc = -((double)NDW * 0x1.00000002p-31);
-  k.kh = (double)Kn + (double)NDW / 2.0;
-  k.xbase = dcs + Kn;
+  k.c = (double)NDW * 0x1.00000002p-31;
+  k.k2 = ((double)(dcs + 65536) - (double)NDW / 2.0 + 1.0) - 1e-10;
   return k;
 }
-__device__ __forceinline__ int vs_noise_w_minus(const VsNoiseK &k, uint32_t r)
+/* the sample's int16 value is the low half of the result */
+__device__ __forceinline__ int vs_noise_sample(const VsNoiseK &k, uint32_t r)
 {
-  return (int)__builtin_fma((double)r, k.negc, k.kh); /* = Kn - w */
+  return (int)__builtin_fma((double)r, k.c, k.k2);
 }
 
 /*
@@ -649,7 +652,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         vs_philox2(b, rk, o);
         int xv[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) xv[w] = nk.xbase - vs_noise_w_minus(nk, o[w] >> 1);
+        for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
         /* T3 + q0 >= 1: VS_DF_FAST lanes have T2 >= 4.  Words in front of the cycle's first
          * noise draw (q0 + w < 0) go to the trash rows. */
         const VsRun8 r8 = vs_run8_or_trash(m > 0, ring, s.wpos, C, T3 + q0, lane);
@@ -675,7 +678,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         vs_philox2(b, rk, o);
         int xv[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) xv[w] = nk.xbase - vs_noise_w_minus(nk, o[w] >> 1);
+        for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
         const VsRun8 r8 = vs_run8_or_trash(q0 < m, ring, s.wpos, C, T3 + q0, lane);
         vs_run8_store_all(r8, xv);
         q0 += 8;
@@ -1319,9 +1322,9 @@ extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t 
  *       perfect square up to 2^24 and its two float neighbours;
  *   [3] vs_round2int(x) against a literal transcription of vowel_new.c:413-427 on a grid around
  *       every half-integer and the clamp edges, tiny negative values and the neighbours of -0.5;
- *   [4] the one-fma noise sample (vs_noise_w_minus) against the reference's
- *       (short)ceil((r/RAND_MAX)*N - N/2.) for ALL 2^31 draws at 16 widths N, and for every
- *       width 0..VS_NDW_FAST at the edge draws;
+ *   [4] the one-fma noise sample (vs_noise_sample) against the reference's
+ *       (short)DC + (short)ceil((r/RAND_MAX)*N - N/2.) for ALL 2^31 draws at 16 (width, DC) pairs,
+ *       and for every width 0..VS_NDW_FAST at the edge draws;
  *   [5] vs_philox2 (prepared round keys, two blocks) against vs_philox.
  * bad[k] counts failures of check k.
  */
@@ -1379,20 +1382,22 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     if (vs_round2int(-tiny) != vs_round2int_literal(-tiny)) b3++;
   }
   {
-    const int widths[16] = {1, 2, 3, 7, 100, 2801, 2802, 4095, 4096, 12345, 32767, 32768, 50001, 65532, 65533, VS_NDW_FAST};
+    const int widths[16] = {1, 2, 3, 7, 100, 2801, 2802, 4095, 4096, 12345, 32767, 32768, 45001, 65534, 45533, 45534};
+    const int dcv[16] = {0, 1, -1, 9830, 0, 0, 3, -3, 0, 0, 16000, -16000, 9830, 0, 9830, -9830};
     for (int wi = 0; wi < 16; ++wi) {
-      const int N = widths[wi];
-      const VsNoiseK nk = vs_noise_consts(N, 0);
-      const int Kn = (N >> 1) + 1;
+      const int N = widths[wi], dc = dcv[wi];
+      const VsNoiseK nk = vs_noise_consts(N, dc);
       for (unsigned long long r = tid; r < (1ull << 31); r += nthreads)
-        if (Kn - vs_noise_w_minus(nk, (uint32_t)r) != vs_noise_w_literal((uint32_t)r, N)) b4++;
+        if ((int)(int16_t)vs_noise_sample(nk, (uint32_t)r) != dc + vs_noise_w_literal((uint32_t)r, N)) b4++;
     }
     const uint32_t edge[12] = {0u, 1u, 2u, 3u, 0x3FFFFFFFu, 0x40000000u, 0x40000001u, 0x7FFFFFFCu, 0x7FFFFFFDu, 0x7FFFFFFEu, 0x7FFFFFFFu, 0x12345678u};
     for (unsigned long long k = tid; k < (unsigned long long)(VS_NDW_FAST + 1) * 12ull; k += nthreads) {
       const int N = (int)(k / 12ull);
       const uint32_t r = edge[k % 12ull];
-      const VsNoiseK nk = vs_noise_consts(N, 0);
-      if (((N >> 1) + 1) - vs_noise_w_minus(nk, r) != vs_noise_w_literal(r, N)) b4++;
+      const int dc = (N & 1) ? 0 : 7;
+      const VsNoiseK nk = vs_noise_consts(N, dc);
+      /* widths near the limit leave no room for DC: compare modulo 2^16, as the store does */
+      if ((int)(int16_t)vs_noise_sample(nk, r) != (int)(int16_t)(dc + vs_noise_w_literal(r, N))) b4++;
     }
   }
   for (unsigned long long k = tid; k < 65536ull; k += nthreads) {
