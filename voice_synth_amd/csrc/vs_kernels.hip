@@ -1,10 +1,12 @@
 /*
  * vs_kernels.hip -- gfx950 (MI355X) kernels of the batched vowel synthesiser.
  *
- * Mapping: ONE UTTERANCE PER LANE, one 64-lane wavefront per workgroup.  The wavefront is
- * CYCLE-MAJOR: lanes do not share a sample clock.  Each lane owns a column of an int16 ring in
- * LDS (layout [slot][lane], 128 B per slot; a lane only ever touches its own column) and its
- * own position n in its own utterance.  The wavefront alternates between
+ * Mapping: ONE UTTERANCE PER LANE, 64 utterances per group.  A group is served either by one
+ * wavefront that alternates between generating and filtering (vs_synth_kernel) or by a generator
+ * wavefront and a filter wavefront (vs_synth_ws_kernel, the default for the fused kind).  Either
+ * way the work is CYCLE-MAJOR: lanes do not share a sample clock.  Each lane owns a column of
+ * an int16 ring in LDS (layout [slot][lane], 128 B per slot; a lane only ever touches its own
+ * column) and its own position n in its own utterance.  The two kinds of work:
  *
  *   generator round (reference flowgen_shimmer.c:246-423): every lane with room produces its
  *       next glottal cycle -- jitter / shimmer recursions with their rejection loops, rising
@@ -1069,13 +1071,16 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 /*
  * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts -- one only
  * generates (vs_cycle_scalars + vs_cycle_emit), the other only filters (vs_superstep) -- coupled
- * through the LDS ring and two per-lane progress words.  A workgroup holds one or two such pairs.
- *
- * When: the plan picks it for grids that leave at least half of the chip's SIMDs empty (e.g.
- * BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024 SIMDs).
- * Every wavefront then has a SIMD of its own and a launch takes max(generator, filter) instead
- * of their sum (1.35-1.6x).  On a full grid it would put two waves on
- * every SIMD; measured, that is no faster than the one-wave kernel, which stays the default.
+ * through the LDS ring and two per-lane progress words.  A workgroup holds one, two or four such
+ * pairs.  This is what the fused kind launches by default (vs_plan_create):
+ *   - grids that leave at least half of the chip's SIMDs empty (e.g. BASELINE config 4 sharded
+ *     over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024 SIMDs): every wavefront has a
+ *     SIMD of its own and a launch takes max(generator, filter) instead of their sum (1.35-1.6x);
+ *   - full grids (BASELINE config 3): four pairs per 512-thread workgroup, wavefronts laid out
+ *     role-major so that every SIMD hosts the generator and the filter of one pair, the filter
+ *     wavefront at raised priority.  One wavefront alone issues an instruction every ~5.3 cycles
+ *     and the pipe is free after 4; two fill each other's gaps (13 % faster than the one-wave
+ *     kernel; pair-major workgroups without the priority were no faster).
  *
  * Hand-off (workgroup scope, LDS only):
  *   gpub[l] = samples lane l's generator has written to the ring   (written by wave 0)
