@@ -142,20 +142,14 @@ def test_mixed_batch_every_option_combination(engine):
     assert np.array_equal(got, want), int((got != want).sum())
 
 
-def test_random_parameter_fuzz(engine):
-    """600 lanes with randomly drawn command lines over the whole option space the reference
-    accepts (seeded): rates, F0/Fg, closed quotient, closure speed and its variation, jitter up
-    to the 10 % limit, shimmer, SNR, DC flow, amplitude, every vowel table, gain, pre-emphasis,
-    output noise.  One batch, bit-exact against the oracle."""
-    rng = np.random.default_rng(424242)
+def _fuzz_lanes(seed, count, dur="0.5"):
+    rng = np.random.default_rng(seed)
     lanes = []
-    tries = 0
-    while len(lanes) < 600:
-        tries += 1
+    while len(lanes) < count:
         fs = int(rng.choice([8000, 11025, 16000, 32000, 44100]))
         f0 = float(rng.uniform(60, 400))
         fg = f0 * float(rng.uniform(1.01, 1.5)) + 0.5
-        fa = ["-r", str(fs), "-d", "0.5", "-f", "%.2f" % f0, "-g", "%.2f" % fg]
+        fa = ["-r", str(fs), "-d", dur, "-f", "%.2f" % f0, "-g", "%.2f" % fg]
         if rng.random() < 0.6:
             fa += ["-j", "%.2f" % rng.uniform(0, 10)]
         if rng.random() < 0.6:
@@ -180,7 +174,7 @@ def test_random_parameter_fuzz(engine):
         if rng.random() < 0.3:
             va += ["-n", "%.1f" % rng.uniform(1, 40)]
         try:
-            lane, dur = vs.lane_from_cli(fa, va, int(rng.integers(0, 2**63)))
+            lane, d = vs.lane_from_cli(fa, va, int(rng.integers(0, 2**63)))
         except vs.VsError:
             continue                      # the reference would answer usage(), e.g. F0 < 50 after rounding
         if vs.load().vs_lane_validate(C.byref(lane)) != 0:
@@ -188,6 +182,15 @@ def test_random_parameter_fuzz(engine):
         if int(np.float32(lane.fs) / np.float32(lane.F0)) * 1.2 > 500:
             continue                      # long periods next to 64 different cos rows exceed the LDS (tested separately)
         lanes.append(lane)
+    return lanes
+
+
+def test_random_parameter_fuzz(engine):
+    """600 lanes with randomly drawn command lines over the whole option space the reference
+    accepts (seeded): rates, F0/Fg, closed quotient, closure speed and its variation, jitter up
+    to the 10 % limit, shimmer, SNR, DC flow, amplitude, every vowel table, gain, pre-emphasis,
+    output noise.  One batch, bit-exact against the oracle."""
+    lanes = _fuzz_lanes(424242, 600)
     n = 6000
     got = engine.synth(lanes, n)
     want = po.synth(lanes, n)
@@ -195,3 +198,31 @@ def test_random_parameter_fuzz(engine):
     assert bad.size == 0, "lanes %s differ" % bad[:10]
     flow = engine.source(lanes, n)
     assert np.array_equal(flow, po.source(lanes, n))
+
+
+@pytest.mark.parametrize("kernel", [vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE])
+def test_random_parameter_fuzz_large(kernel):
+    """the same draw of command lines at scale: 12000 lanes (lanes that take the generator's short
+    sequences next to lanes that cannot, every option on and off), every sample against the oracle,
+    with the default kernel choice and with the one-wave kernel forced"""
+    lanes = _fuzz_lanes(20261004, 12000)
+    n = 5000
+    eng = vs.Engine(0)
+    eng.set_tuning(kernel=kernel)
+    try:
+        got = eng.synth(lanes, n)
+    finally:
+        eng.close()
+    bad = 0
+    for lo in range(0, len(lanes), 4000):
+        want = po.synth(lanes[lo:lo + 4000], n, threads=32)
+        bad += int((got[lo:lo + 4000] != want).any(axis=1).sum())
+    fast = sum(1 for l in lanes[:2000] if _is_fast(l))
+    print("fuzz: %d of the first 2000 lanes take the short sequences" % fast)
+    assert bad == 0, "%d lanes differ" % bad
+
+
+def _is_fast(lane):
+    d = vs._ffi.DevLane()
+    vs.load().vs_expand_lane(C.byref(lane), 0, C.byref(d))
+    return bool(d.flags & vs._ffi.VS_DF_FAST)
