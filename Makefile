@@ -57,7 +57,7 @@ resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(CSRC)/vs_kernels.hip
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) $(LIBDIR)/libvoicesynth_diag.so $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
+	rm -f $(CSRC)/*.o $(LIB) $(LIBDIR)/libvoicesynth_*.so $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
 	$(MAKE) -C oracle clean
 
 .PHONY: all clis oracle resources clean diag
