@@ -49,6 +49,7 @@ ALGO_BYTES_PER_SAMPLE = 2       # one int16 store; the flow never reaches HBM (S
 FLOP_PER_SAMPLE = 48            # 22 mul + 22 sub + gain + pre-emphasis mul/sub
 GATHER_CHUNK = 16384            # utterances per chunk of the pipelined gather
 GATHER_DEADLINE_S = 150         # the gather leg may not hold the benchmark line longer than this
+TEARDOWN_DEADLINE_S = 60        # nor may the closing barrier hold the process once the line is printed
 
 
 def parse_args():
@@ -434,6 +435,14 @@ def main():
 
     leg_done.set()
     emit()
+
+    if use_dist:
+        # the line is out; a peer that left early (its own gather leg failed) must not hold the
+        # others in the closing barrier
+        def leave():
+            time.sleep(TEARDOWN_DEADLINE_S)
+            os._exit(0)
+        threading.Thread(target=leave, daemon=True).start()
 
     plan.close()
     eng.close()
