@@ -226,3 +226,48 @@ def _is_fast(lane):
     d = vs._ffi.DevLane()
     vs.load().vs_expand_lane(C.byref(lane), 0, C.byref(d))
     return bool(d.flags & vs._ffi.VS_DF_FAST)
+
+
+def test_config4_whole_batch_on_one_device(engine):
+    """ALL of BASELINE config 4 on one device: 262144 utterances x 44100 samples = 23.1 GB of PCM
+    left in HBM (row offsets beyond 2^32 bytes, 4096 wavefront groups).  Sampled rows -- first,
+    last, both sides of every 4 GiB boundary of the output -- against the oracle, and every row of
+    the first and last per-GPU shard against the shard computed on its own."""
+    n_lanes = 262144
+    specs, fs, dur, _ = configs.config_specs(4, n_lanes)
+    lanes, d = vs.lanes_from_specs(specs)
+    n = vs.num_samples(fs, d)
+    assert n == 44100
+    pitch = (n + 7) & ~7
+    row_bytes = pitch * 2
+    buf = engine.dev_alloc(n_lanes * row_bytes)
+    try:
+        plan = engine.plan(lanes, n)
+        try:
+            plan.launch(vs.VS_KIND_SYNTH, buf, out_pitch=pitch)
+            plan.status()
+        finally:
+            plan.close()
+
+        def row(i):
+            return engine.dev_download(buf + i * row_bytes, (pitch,))[:n]
+
+        pick = {0, 1, 63, 64, n_lanes - 1, n_lanes - 64}
+        for k in range(1, (n_lanes * row_bytes) >> 32):
+            edge = (k << 32) // row_bytes
+            pick |= {edge - 1, edge, edge + 1}
+        pick |= set(range(777, n_lanes, 9973))
+        pick = sorted(pick)
+        want = po.synth([lanes[i] for i in pick], n)
+        for j, i in enumerate(pick):
+            assert np.array_equal(row(i), want[j]), i
+        # placement: a per-GPU shard computed on its own equals its rows of the whole batch
+        for shard in (0, 7):
+            lo = shard * 32768
+            sub = (vs.Lane * 32768)()
+            C.memmove(sub, C.byref(lanes, lo * C.sizeof(vs.Lane)), 32768 * C.sizeof(vs.Lane))
+            got = engine.synth(sub, n)
+            whole = engine.dev_download(buf + lo * row_bytes, (32768, pitch))[:, :n]
+            assert np.array_equal(got, whole), shard
+    finally:
+        engine.dev_free(buf)

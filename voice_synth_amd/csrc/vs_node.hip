@@ -166,10 +166,11 @@ void shard_gather(ShardJob *j)
   }
   VsPool &P = ctx->pool;
   const size_t rows_all = j->hi - j->lo;
-  const size_t chunk = std::min<size_t>(rows_all, VS_NODE_CHUNK);
   const size_t pitch = (j->n_samples + 7) & ~(size_t)7;
-  /* the root's own shard is synthesised in place when the destination rows allow 16-byte stores */
+  /* the root's own shard is synthesised in place, in ONE launch: nothing travels, so there is
+   * nothing to overlap, and a whole shard fills the chip where a chunk fills a quarter of it */
   const bool in_place = (nd->device[s] == nd->device[0]) && !(j->flags & VS_NODE_STAGE_ALL);
+  const size_t chunk = in_place ? rows_all : std::min<size_t>(rows_all, VS_NODE_CHUNK);
   if (!in_place) {
     for (int k = 0; k < 2 && (k == 0 || rows_all > chunk); k++) {
       j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
