@@ -74,6 +74,14 @@ def main():
     add("onoise_22k", ["-d", "2", "-j", "1", "-n", "10"], ["-v", "4", "-g", "2", "-n", "5"], 21)
     add("onoise_frac", ["-r", "11025", "-d", "0.77"], ["-v", "a", "-n", "35", "-p", "0.3"], 22)
     add("edge_seed64", g16 + ["-j", "1", "-s", "5.76", "-n", "20"], ["-v", "4"], 0xFEDCBA9876543210)
+    # --- T4 carried from cycle to cycle (flowgen_shimmer.c:114 is never reset): zero DC flow, so only
+    #     a cycle whose amplitude passes 32767 and wraps the (short) conversion sets T4 (fg:319-323);
+    #     every later cycle adds noise to [0, T4) and takes its power over [T4, T3) (fg:375-400) ---
+    add("carry_t4_k119", ["-r", "11025", "-d", "0.6", "-f", "267.26", "-g", "367.88", "-c", "0.40", "-k", "1.19",
+                          "-a", "27080", "-s", "16.67", "-n", "39.2", "-l", "0"], ["-v", "5"], 3)
+    add("carry_t4_jit", g16 + ["-a", "30000", "-s", "10", "-n", "20", "-l", "0", "-j", "1"], ["-v", "a", "-g", "1"], 1)
+    add("carry_t4_22k", ["-d", "0.5", "-a", "32000", "-s", "3", "-n", "10", "-l", "0", "-z", "0.3"],
+        ["-v", "3", "-g", "2", "-p", "0.5"], 1, keep=False)
 
     manifest = []
     arrays = {}
@@ -101,7 +109,7 @@ def main():
               (name, entry["n_samples"], entry["ndraws"], entry["sha256_flow"][:16], entry["sha256_pcm"][:16]))
 
     # -O2 build of the reference must agree with the -O0 build
-    for name, fa, va, seed, keep in cases[:3] + cases[-3:]:
+    for name, fa, va, seed, keep in cases[:3] + cases[-6:]:
         r2 = po.run_reference(fa, va, seed, opt="O2")
         e = [m for m in manifest if m["name"] == name][0]
         assert sha(r2["flow"]) == e["sha256_flow"] and sha(r2["pcm"]) == e["sha256_pcm"], name

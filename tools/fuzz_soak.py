@@ -1,0 +1,57 @@
+"""Soak run of the parameter fuzz (tests/test_gpu_properties.py::_fuzz_lanes) over many seeds:
+every sample of every lane against the CPU oracle, default kernel choice and one-wave kernel,
+plus the source-only kind.  Needs the GPU; the oracle is the checker.
+
+    python tools/fuzz_soak.py [first_seed] [n_seeds] [lanes] [samples]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import voice_synth_amd as vs  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from test_gpu_properties import _fuzz_lanes  # noqa: E402
+
+
+def main():
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    n_lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+    bad_total = 0
+    lanes_total = 0
+    t0 = time.time()
+    for seed in range(seed0, seed0 + n_seeds):
+        lanes = _fuzz_lanes(seed, n_lanes)
+        want = po.synth(lanes, n, threads=32)
+        want_flow = po.source(lanes, n, threads=32)
+        for kernel in (vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE):
+            eng = vs.Engine(0)
+            eng.set_tuning(kernel=kernel)
+            try:
+                got = eng.synth(lanes, n)
+                flow = eng.source(lanes, n) if kernel == vs.VS_KERNEL_AUTO else None
+            finally:
+                eng.close()
+            bad = int((got != want).any(axis=1).sum())
+            if flow is not None:
+                bad += int((flow != want_flow).any(axis=1).sum())
+            bad_total += bad
+            if bad:
+                rows = np.flatnonzero((got != want).any(axis=1))[:5]
+                print("seed %d kernel %d: %d lanes differ, first rows %s" % (seed, kernel, bad, rows), flush=True)
+        lanes_total += len(lanes)
+        print("seed %d: %d lanes x %d samples, both kernels + source: %s  (%.0f s)"
+              % (seed, len(lanes), n, "ok" if bad_total == 0 else "DIFFERENCES", time.time() - t0), flush=True)
+    print("soak: %d lanes over %d seeds, %d differing lanes" % (lanes_total, n_seeds, bad_total))
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

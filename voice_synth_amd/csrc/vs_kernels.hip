@@ -494,7 +494,10 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         const int xs = lt ? c.dcs : xs0[k];
         const float xf = lt ? dcsf : xf0[k];
         T4 = lt ? (i + k) : T4;
-        psum = (lt ? 0.0f : psum) + xf * xf;
+        /* aux of fg:375 runs over [T4, T3) with the FINAL T4 -- which is a T4 carried over from an
+         * earlier cycle when this cycle never goes below DC (the variable is never reset, fg:114):
+         * samples in front of it do not count */
+        psum = lt ? (xf * xf) : ((i + k >= T4) ? (psum + xf * xf) : psum);
         ring[vs_ring_at(s.wpos, C, i + k, lane)] = (int16_t)xs;
       }
     }
@@ -505,7 +508,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
       const int xs = lt ? c.dcs : xs0;
       const float xf = lt ? dcsf : xf0;
       T4 = lt ? i : T4;
-      psum = (lt ? 0.0f : psum) + xf * xf;
+      psum = lt ? (xf * xf) : ((i >= T4) ? (psum + xf * xf) : psum);
       if (i < lim) ring[vs_ring_at(s.wpos, C, i, lane)] = (int16_t)xs;
     }
   }
