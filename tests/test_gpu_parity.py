@@ -68,6 +68,32 @@ def test_filter_only_bit_exact(engine):
     assert np.array_equal(got, want)
 
 
+def test_filter_decay_into_denormals(engine):
+    """vowel_new.c:413-427 returns 1 -- not 0 -- for a result in (-2^-54, 0): dec = x - floor(x)
+    rounds to 1.0, x + 1 rounds to 1.0.  After an impulse the recurrence decays through the
+    denormal range and keeps oscillating there, so the reference's output is a long pattern of
+    0s and 1s that only an identical double state (denormals included) reproduces."""
+    lanes = []
+    for v in "aiu1234567":
+        for g, p in (("1", "1"), ("10", "0"), ("3", "0.5")):
+            lane, _ = vs.lane_from_cli(["-r", "16000", "-d", "1"], ["-v", v, "-g", g, "-p", p], 1)
+            lanes.append(lane)
+    n = 400000
+    flow = np.zeros((len(lanes), n), dtype=np.int16)
+    flow[:, 0] = 20000
+    flow[:, 1000] = -3
+    want = po.filter(lanes, flow)
+    assert int((want[:, 100000:] == 1).sum()) > 100000       # the regime is reached
+    got = engine.filter(lanes, flow)
+    assert np.array_equal(got, want)
+    engine.set_arith(vs.VS_ARITH_FMA)
+    try:
+        fma = engine.filter(lanes, flow)
+    finally:
+        engine.set_arith(vs.VS_ARITH_EXACT)
+    assert np.abs(fma.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
 def test_cycle_log_matches_oracle(engine):
     lanes, ns = _lanes(3, 5)
     flow, recs, ncyc = engine.source(lanes, ns, log_cycles=400)

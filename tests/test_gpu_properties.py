@@ -185,6 +185,56 @@ def _fuzz_lanes(seed, count, dur="0.5"):
     return lanes
 
 
+def _pick(rng, ends, lo, hi, fmt):
+    """an end point / special value with probability 1/2, otherwise uniform over [lo, hi]"""
+    if rng.random() < 0.5:
+        return ends[int(rng.integers(0, len(ends)))]
+    return fmt % rng.uniform(lo, hi)
+
+
+def _corner_lanes(seed, count):
+    rng = np.random.default_rng(seed)
+    lanes = []
+    while len(lanes) < count:
+        fs = int(rng.choice([8000, 11025, 16000, 32000, 44100, 48000]))
+        f0 = float(_pick(rng, ["50", "50.01", "120", "399.99"], 50, 400, "%.2f"))
+        fg = f0 * float(rng.choice([1.0001, 1.04, 1.5, 10.0])) + float(rng.choice([0.01, 1.0]))
+        fa = ["-r", str(fs), "-d", "0.5", "-f", "%.2f" % f0, "-g", "%.2f" % fg]
+        if rng.random() < 0.6:
+            fa += ["-j", _pick(rng, ["0", "0.01", "10", "50", "200", "1000"], 0, 10, "%.2f")]
+        if rng.random() < 0.6:
+            fa += ["-s", _pick(rng, ["0", "0.01", "50", "100"], 0, 30, "%.2f")]
+        if rng.random() < 0.7:
+            fa += ["-n", _pick(rng, ["0", "0.1", "50"], 0, 50, "%.1f")]
+        if rng.random() < 0.6:
+            fa += ["-l", _pick(rng, ["0", "0.001", "0.3"], 0, 0.3, "%.3f")]
+        if rng.random() < 0.5:
+            fa += ["-z", _pick(rng, ["0", "1"], 0, 1, "%.2f")]
+        if rng.random() < 0.6:
+            fa += ["-k", _pick(rng, ["0.5", "1", "2", "5", "40"], 0.5, 1.2, "%.2f")]
+        if rng.random() < 0.6:
+            fa += ["-c", _pick(rng, ["0.01", "0.05", "1"], 0.05, 1.0, "%.2f")]
+        if rng.random() < 0.7:
+            fa += ["-a", _pick(rng, ["0", "1", "2", "50", "32766", "30000"], 1, 32766, "%.0f")]
+        va = ["-v", str(rng.choice(list("aiu1234567")))]
+        if rng.random() < 0.5:
+            va += ["-g", _pick(rng, ["1", "100", "1000"], 1, 20, "%.2f")]
+        if rng.random() < 0.5:
+            va += ["-p", _pick(rng, ["0", "1"], 0, 1, "%.2f")]
+        if rng.random() < 0.3:
+            va += ["-n", _pick(rng, ["0.1", "60"], 1, 40, "%.1f")]
+        try:
+            lane, d = vs.lane_from_cli(fa, va, int(rng.integers(0, 2**63)))
+        except vs.VsError:
+            continue                      # the reference would answer usage()
+        if vs.load().vs_lane_validate(C.byref(lane)) != 0:
+            continue                      # e.g. a closed quotient that leaves no pulse
+        if int(np.float32(lane.fs) / np.float32(lane.F0)) * 1.2 > 500:
+            continue                      # long periods next to 64 different cos rows exceed the LDS
+        lanes.append(lane)
+    return lanes
+
+
 def test_random_parameter_fuzz(engine):
     """600 lanes with randomly drawn command lines over the whole option space the reference
     accepts (seeded): rates, F0/Fg, closed quotient, closure speed and its variation, jitter up
@@ -220,6 +270,26 @@ def test_random_parameter_fuzz_large(kernel):
     fast = sum(1 for l in lanes[:2000] if _is_fast(l))
     print("fuzz: %d of the first 2000 lanes take the short sequences" % fast)
     assert bad == 0, "%d lanes differ" % bad
+
+
+def test_corner_parameter_fuzz():
+    """every option drawn from the END POINTS of the range the reference's parser accepts, mixed with
+    ordinary values (zero DC flow, amplitude 0 / 1 / 32766, jitter up to the parser's real limit of
+    1000 %, shimmer 100 %, closing speed 40, closed quotient 1, SNR 0 and 50 dB, gain 1000): rare
+    settings in combination are the rule here.  tools/fuzz_soak.py runs the same generator over
+    many seeds."""
+    lanes = _corner_lanes(31337, 8000)
+    n = 5000
+    want = po.synth(lanes, n, threads=32)
+    for kernel in (vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE):
+        eng = vs.Engine(0)
+        eng.set_tuning(kernel=kernel)
+        try:
+            got = eng.synth(lanes, n)
+        finally:
+            eng.close()
+        bad = int((got != want).any(axis=1).sum())
+        assert bad == 0, "%d lanes differ (kernel %d)" % (bad, kernel)
 
 
 def _is_fast(lane):

@@ -2,7 +2,13 @@
 every sample of every lane against the CPU oracle, default kernel choice and one-wave kernel,
 plus the source-only kind.  Needs the GPU; the oracle is the checker.
 
-    python tools/fuzz_soak.py [first_seed] [n_seeds] [lanes] [samples]
+    python tools/fuzz_soak.py [first_seed] [n_seeds] [lanes] [samples] [uniform|corners]
+
+"uniform" draws every option uniformly over its usual range (the generator of the test suite);
+"corners" draws every option from the END POINTS of the range the reference's parser accepts
+(flowgen_shimmer.c:470-546, vowel_new.c:123-187) mixed with ordinary values -- zero DC flow, amplitudes 0, 1
+and 32766, jitter up to the parser's real limit of 1000 %, shimmer 100 %, closing speeds far above 1,
+closed quotient 1, SNR 0 and 50 dB -- so that combinations of rare settings are the rule.
 """
 import os
 import sys
@@ -16,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import voice_synth_amd as vs  # noqa: E402
 from oracle import pyoracle as po  # noqa: E402
-from test_gpu_properties import _fuzz_lanes  # noqa: E402
+from test_gpu_properties import _corner_lanes, _fuzz_lanes  # noqa: E402
 
 
 def main():
@@ -24,11 +30,12 @@ def main():
     n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n_lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+    gen = _corner_lanes if (len(sys.argv) > 5 and sys.argv[5] == "corners") else _fuzz_lanes
     bad_total = 0
     lanes_total = 0
     t0 = time.time()
     for seed in range(seed0, seed0 + n_seeds):
-        lanes = _fuzz_lanes(seed, n_lanes)
+        lanes = gen(seed, n_lanes)
         want = po.synth(lanes, n, threads=32)
         want_flow = po.source(lanes, n, threads=32)
         for kernel in (vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE):
