@@ -1,0 +1,44 @@
+"""VS_ARITH_FMA over the parameter fuzz: how far the fused-multiply-add recurrence gets from the
+exact one (the oracle) -- maximum |difference| in LSB, differing samples, RMS on the /32768 scale.
+
+    python tools/fuzz_fma.py [first_seed] [n_seeds] [lanes] [samples]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import voice_synth_amd as vs  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from test_gpu_properties import _corner_lanes, _fuzz_lanes  # noqa: E402
+
+
+def main():
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    n_lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+    eng = vs.Engine(0, arith=vs.VS_ARITH_FMA)
+    worst = 0
+    for name, gen in (("uniform", _fuzz_lanes), ("corners", _corner_lanes)):
+        for seed in range(seed0, seed0 + n_seeds):
+            lanes = gen(seed, n_lanes)
+            want = po.synth(lanes, n, threads=32).astype(np.int32)
+            got = eng.synth(lanes, n).astype(np.int32)
+            d = got - want
+            nd = int(np.count_nonzero(d))
+            mx = int(np.abs(d).max())
+            worst = max(worst, mx)
+            rms = float(np.sqrt(np.mean((d / 32768.0) ** 2)))
+            print("%s seed %d: %d of %d samples differ, max |d| %d LSB, rms %.2e" % (name, seed, nd, d.size, mx, rms), flush=True)
+    eng.close()
+    print("worst |difference| %d LSB" % worst)
+    return 0 if worst <= 1 else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

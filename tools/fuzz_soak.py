@@ -25,6 +25,10 @@ from oracle import pyoracle as po  # noqa: E402
 from test_gpu_properties import _corner_lanes, _fuzz_lanes  # noqa: E402
 
 
+LOG_LANES = 1500   # lanes per seed whose cycle records are compared
+LOG_CAP = 700      # records kept per lane (0.5 s at 400 Hz is 200 cycles; jitter can shorten them)
+
+
 def main():
     seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -53,6 +57,26 @@ def main():
             if bad:
                 rows = np.flatnonzero((got != want).any(axis=1))[:5]
                 print("seed %d kernel %d: %d lanes differ, first rows %s" % (seed, kernel, bad, rows), flush=True)
+        # the per-cycle records of the single-utterance programs (S, x_pow, w_pow, T: what the
+        # reference prints, flowgen_shimmer.c:307,409) come from a different instantiation of the
+        # generator (no short sequences): a slice of the lanes through it
+        sub = lanes[:LOG_LANES]
+        eng = vs.Engine(0)
+        try:
+            flow, recs, ncyc = eng.source(sub, n, log_cycles=LOG_CAP)
+        finally:
+            eng.close()
+        bad = int((flow != want_flow[:len(sub)]).any(axis=1).sum())
+        for i, lane in enumerate(sub):
+            _, wrecs, wn, _ = po.source_one(lane, n, LOG_CAP)
+            k = min(wn, LOG_CAP)
+            same = int(ncyc[i]) == wn
+            for f in ("S", "x_pow", "w_pow", "T"):
+                same = same and np.array_equal(recs[i][f][:k], wrecs[f][:k], equal_nan=(f != "T"))
+            if not same:
+                bad += 1
+                print("seed %d lane %d: cycle records differ" % (seed, i), flush=True)
+        bad_total += bad
         lanes_total += len(lanes)
         print("seed %d: %d lanes x %d samples, both kernels + source: %s  (%.0f s)"
               % (seed, len(lanes), n, "ok" if bad_total == 0 else "DIFFERENCES", time.time() - t0), flush=True)
