@@ -142,7 +142,8 @@ def test_mixed_batch_every_option_combination(engine):
     assert np.array_equal(got, want), int((got != want).sum())
 
 
-def _fuzz_lanes(seed, count, dur="0.5"):
+def _fuzz_lanes(seed, count, dur="0.5", specs=None):
+    """specs, when given, receives the (flowgen args, vowel args, seed) of every lane kept"""
     rng = np.random.default_rng(seed)
     lanes = []
     while len(lanes) < count:
@@ -182,6 +183,8 @@ def _fuzz_lanes(seed, count, dur="0.5"):
         if int(np.float32(lane.fs) / np.float32(lane.F0)) * 1.2 > 500:
             continue                      # long periods next to 64 different cos rows exceed the LDS (tested separately)
         lanes.append(lane)
+        if specs is not None:
+            specs.append((fa, va, int(lane.seed)))
     return lanes
 
 
@@ -192,7 +195,7 @@ def _pick(rng, ends, lo, hi, fmt):
     return fmt % rng.uniform(lo, hi)
 
 
-def _corner_lanes(seed, count):
+def _corner_lanes(seed, count, specs=None):
     rng = np.random.default_rng(seed)
     lanes = []
     while len(lanes) < count:
@@ -232,6 +235,8 @@ def _corner_lanes(seed, count):
         if int(np.float32(lane.fs) / np.float32(lane.F0)) * 1.2 > 500:
             continue                      # long periods next to 64 different cos rows exceed the LDS
         lanes.append(lane)
+        if specs is not None:
+            specs.append((fa, va, int(lane.seed)))
     return lanes
 
 

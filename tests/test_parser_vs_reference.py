@@ -145,3 +145,32 @@ def test_vowel_argv_fuzz_against_the_compiled_reference():
         assert np.array_equal(want, pcm), argv
         accepted += 1
     assert accepted > 40 and rejected > 40, (accepted, rejected)
+
+
+def _reference_defined(lane):
+    """the reference's heap block x holds 2*fs/Fg samples (flowgen_shimmer.c:569) and w[] 500
+    (fg:115): a period beyond either is an overrun there"""
+    tmax = int(1.2 * int(np.float32(lane.fs) / np.float32(lane.F0))) + 2
+    return tmax <= int(lane.fs / lane.Fg * 2) and tmax <= 500
+
+
+@pytest.mark.parametrize("draw", ["uniform", "corners"])
+def test_oracle_against_the_compiled_reference_over_the_option_fuzz(draw):
+    """the generators of the GPU fuzz (tests/test_gpu_properties.py) feed the GPU-vs-oracle tests;
+    here the SAME draws pin the oracle to the compiled reference: flow and speech, byte for byte"""
+    from test_gpu_properties import _corner_lanes, _fuzz_lanes
+    specs = []
+    lanes = (_fuzz_lanes if draw == "uniform" else _corner_lanes)(97531, 400, specs=specs)
+    compared = 0
+    for lane, (fa, va, seed) in zip(lanes, specs):
+        if not _reference_defined(lane):
+            continue
+        ref = po.run_reference(fa, va, seed)
+        n = len(ref["flow"])
+        assert n == vs.num_samples(lane.fs, 0.5)
+        flow, _, _, nd = po.source_one(lane, n)
+        assert np.array_equal(flow, ref["flow"]), (fa, seed)
+        assert nd == ref["ndraws"], (fa, seed)
+        assert np.array_equal(po.filter([lane], flow[None, :])[0], ref["pcm"]), (fa, va, seed)
+        compared += 1
+    assert compared > 100, compared
