@@ -154,20 +154,23 @@ def _reference_defined(lane):
     return tmax <= int(lane.fs / lane.Fg * 2) and tmax <= 500
 
 
-@pytest.mark.parametrize("draw", ["uniform", "corners"])
-def test_oracle_against_the_compiled_reference_over_the_option_fuzz(draw):
+@pytest.mark.parametrize("draw,dur", [("uniform", "0.5"), ("corners", "0.5"), ("uniform", "0.83")])
+def test_oracle_against_the_compiled_reference_over_the_option_fuzz(draw, dur):
     """the generators of the GPU fuzz (tests/test_gpu_properties.py) feed the GPU-vs-oracle tests;
     here the SAME draws pin the oracle to the compiled reference: flow and speech, byte for byte"""
     from test_gpu_properties import _corner_lanes, _fuzz_lanes
     specs = []
-    lanes = (_fuzz_lanes if draw == "uniform" else _corner_lanes)(97531, 400, specs=specs)
+    if draw == "uniform":
+        lanes = _fuzz_lanes(97531 + int(float(dur) * 100), 400, dur=dur, specs=specs)
+    else:
+        lanes = _corner_lanes(97531, 400, specs=specs)
     compared = 0
     for lane, (fa, va, seed) in zip(lanes, specs):
         if not _reference_defined(lane):
             continue
         ref = po.run_reference(fa, va, seed)
         n = len(ref["flow"])
-        assert n == vs.num_samples(lane.fs, 0.5)
+        assert n == vs.num_samples(lane.fs, float(dur))
         flow, _, _, nd = po.source_one(lane, n)
         assert np.array_equal(flow, ref["flow"]), (fa, seed)
         assert nd == ref["ndraws"], (fa, seed)
