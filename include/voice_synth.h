@@ -28,12 +28,19 @@
 extern "C" {
 #endif
 
-/* Filter order.  The reference runs Order = 22 for every table (vowel_new.c:172); MAX_ORDER 40
- * (vowel_new.c:33) is only the bound of its arrays.  A VS_VOWEL_CUSTOM coefficient set has
- * exactly 22 taps: lower orders are expressed by trailing zeros (acc - 0*y == acc, so the result
- * equals the reference's loop run with the smaller Order); orders 23..40 are not supported. */
+/* Filter order.  The reference runs Order = 22 for every table (vowel_new.c:172) inside arrays
+ * bounded by MAX_ORDER 40 (vowel_new.c:33); its loop (vowel_new.c:279-281, 287-289) is written for
+ * any Order.  A VS_VOWEL_CUSTOM coefficient set carries its own order (vs_lane.order, 1..40):
+ *   - up to 22 taps it rides the fused kernel like a table (missing taps are zeros: acc - 0*y == acc,
+ *     so the result equals the reference's loop run with the smaller Order);
+ *   - 23..40 taps take the WIDE path: the source kernel writes the flow to HBM and a filter kernel
+ *     with a 48-sample register window reads it back (un-fused: 6 bytes of HBM traffic per sample
+ *     instead of 2, and ~2x the arithmetic).  A plan is wide as a whole as soon as one of its lanes
+ *     is. */
 #define VS_ORDER 22
 #define VS_NCOEF (VS_ORDER + 1)
+#define VS_MAX_ORDER 40
+#define VS_MAX_NCOEF (VS_MAX_ORDER + 1)
 
 /* return codes */
 #define VS_OK 0
@@ -83,7 +90,9 @@ typedef struct vs_lane {
   int32_t vowel;      /* 'a','i','u','1'..'7', or VS_VOWEL_CUSTOM           vw:152 */
   float out_snr;      /* vowel -n: linear SNR pow(10, x/10) of the white noise added to the
                          filtered signal frame by frame, 0 = off                vw:141-143, 302-324 */
-  double A[VS_NCOEF]; /* A(z) when vowel == VS_VOWEL_CUSTOM; A[0] must be 1.0 */
+  double A[VS_MAX_NCOEF]; /* A(z) when vowel == VS_VOWEL_CUSTOM: A[0] must be 1.0, A[1..order] the taps */
+  int32_t order;      /* taps of the VS_VOWEL_CUSTOM set, 1..VS_MAX_ORDER; 0 means VS_ORDER (22) */
+  int32_t reserved_;  /* keeps out_seed 8-byte aligned without implicit padding; must be 0 */
   uint64_t out_seed;  /* Philox key of the vowel stage's own draw stream (the reference's vowel
                          process calls srandom(time) itself, vw:234): one draw per sample */
 } vs_lane;
@@ -100,9 +109,12 @@ typedef struct vs_cycle_rec {
 /* Arithmetic of the filter recurrence.
  * VS_ARITH_EXACT: products and subtractions rounded one by one in the reference's order
  *                 (vowel_new.c:279-281); the double state equals the reference's bit for bit.
- * VS_ARITH_FMA:   22 fused multiply-adds in four partial sums; the double state differs in the
- *                 last bits, so the int16 output is not guaranteed identical (measured: 0
- *                 differences in 1.05e9 samples of BASELINE config 3; bound +-1 LSB). */
+ * VS_ARITH_FMA:   fused multiply-adds in two partial sums; the double state differs in the last
+ *                 bits, so the int16 output is not guaranteed identical.  For the reference's
+ *                 tables: 0 differences in 1.05e9 samples of BASELINE config 3 and in 6e8 samples
+ *                 of the option fuzz, bound +-1 LSB.  For explicit sets the distance follows the
+ *                 set's conditioning (+-1 LSB measured for max |A| <= 500; a direct form of order
+ *                 40 with coefficients of 1e4 moves a few samples by more). */
 #define VS_ARITH_EXACT 0
 #define VS_ARITH_FMA 1
 
@@ -124,6 +136,10 @@ int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples);
 
 /* The denominator tables of coefficients(), vowel_new.c:430-633.  A receives 23 doubles. */
 int vs_vowel_coefficients(int vowel, double *A);
+
+/* Order of the lane's all-pole filter: VS_ORDER for the ten tables, vs_lane.order (1..VS_MAX_ORDER,
+ * 0 = VS_ORDER) for a VS_VOWEL_CUSTOM set; VS_ERR_RANGE beyond MAX_ORDER (vowel_new.c:33). */
+int vs_lane_order(const vs_lane *lane, int *order);
 /* The label coefficients() prints for the entry ("/a/ JPHS", ...), vowel_new.c:550-622. */
 const char *vs_vowel_name(int vowel);
 

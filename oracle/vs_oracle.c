@@ -68,10 +68,21 @@ long vs_oracle_draw(uint64_t seed, uint64_t n)
   return vs_draw_next(&s);
 }
 
+/* Order of vowel_new.c:172 -- 22 for every table; an explicit set carries its own */
+int vs_oracle_order(const vs_lane *lane)
+{
+  if (lane->vowel != VS_VOWEL_CUSTOM) return VS_ORDER;
+  if (lane->order < 0 || lane->order > VS_MAX_ORDER) return -1;
+  return lane->order ? lane->order : VS_ORDER;
+}
+
 int vs_oracle_coefficients(const vs_lane *lane, double *A)
 {
   if (lane->vowel == VS_VOWEL_CUSTOM) {
-    memcpy(A, lane->A, sizeof(double) * VS_NCOEF);
+    /* an explicit set: A[0..order], order = lane->order (0 = 22), at most MAX_ORDER (vowel_new.c:33) */
+    const int order = vs_oracle_order(lane);
+    if (order < 1) return VS_ERR_RANGE;
+    memcpy(A, lane->A, sizeof(double) * (size_t)(order + 1));
     return VS_OK;
   }
   for (int t = 0; t < VS_ORACLE_TAB_NTABLES; t++) {
@@ -224,13 +235,14 @@ int vs_oracle_source(const vs_lane *lane, size_t n_samples, int16_t *flow, vs_cy
  * ---------------------------------------------------------------------------------------- */
 int vs_oracle_filter(const vs_lane *lane, size_t n_samples, const int16_t *flow, int16_t *pcm)
 {
-  double A[VS_NCOEF], B0 = 1.0;
-  double y_double[VS_NCOEF];
+  double A[VS_MAX_NCOEF], B0 = 1.0;   /* MAX_ORDER + 1, vowel_new.c:33,61-63 */
+  double y_double[VS_MAX_NCOEF];
   const float gain = lane->gain, pre_emphasis = lane->pre_emphasis;
   int rc = vs_oracle_coefficients(lane, A);
   if (rc != VS_OK) return rc;
+  const int Order = vs_oracle_order(lane); /* vowel_new.c:172 */
 
-  for (int j = 0; j < VS_ORDER + 1; j++) y_double[j] = 0.0;
+  for (int j = 0; j < Order + 1; j++) y_double[j] = 0.0;
 
   /* frame length, vowel_new.c:361-363 (header.nSamplesPerSec is an unsigned long) */
   const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
@@ -253,13 +265,13 @@ int vs_oracle_filter(const vs_lane *lane, size_t n_samples, const int16_t *flow,
       y_double[0] = 0.0;
       y_double[0] = y_double[0] + B0 * flow[i] * gain;
       /* poles, vowel_new.c:279-281 */
-      for (int j = 1; j < VS_ORDER + 1; j++) {
+      for (int j = 1; j < Order + 1; j++) {
         y_double[0] = y_double[0] - A[j] * y_double[j];
       }
       /* pre-emphasis on the output only, vowel_new.c:284 */
       y[k] = vs_oracle_round2int(y_double[0] - pre_emphasis * y_double[1]);
       /* shift, vowel_new.c:287-289 */
-      for (int j = VS_ORDER; j > 0; j--) {
+      for (int j = Order; j > 0; j--) {
         y_double[j] = y_double[j - 1];
       }
     }

@@ -27,8 +27,11 @@ int vs_oracle_source(const vs_lane *lane, size_t n_samples, int16_t *flow, vs_cy
 /* vowel_new.c:222-224, 266-289, 413-427 for one lane (no vowel -n noise). */
 int vs_oracle_filter(const vs_lane *lane, size_t n_samples, const int16_t *flow, int16_t *pcm);
 
-/* The 23 denominator coefficients the lane selects. */
+/* The denominator coefficients the lane selects: 23 for a table, order + 1 (at most 41) for an
+ * explicit set.  A must hold VS_MAX_NCOEF doubles. */
 int vs_oracle_coefficients(const vs_lane *lane, double *A);
+/* Order of the lane's filter (vowel_new.c:172): 22, or vs_lane.order of an explicit set; -1 beyond MAX_ORDER */
+int vs_oracle_order(const vs_lane *lane);
 
 /* Batches, OpenMP over lanes when threads > 1.  Layout [n_lanes][n_samples]. */
 int vs_oracle_source_batch(const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *flow,

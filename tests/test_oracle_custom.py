@@ -26,15 +26,15 @@ def _round2int(x):
     return int(math.floor(x))
 
 
-def _filter_literal(A, gain, pre, flow):
-    y = [0.0] * 23                        # y_double[], vowel_new.c:222-224
+def _filter_literal(A, gain, pre, flow, order=22):
+    y = [0.0] * (order + 1)               # y_double[], vowel_new.c:222-224
     out = []
     for x in flow:
         y[0] = 0.0 + 1.0 * float(x) * gain  # B = {1, 0, ...}, vowel_new.c:266-269
-        for j in range(1, 23):
+        for j in range(1, order + 1):     # for(j=1; j<Order+1; j++), vowel_new.c:279
             y[0] = y[0] - A[j] * y[j]     # vowel_new.c:279-281
         out.append(_round2int(y[0] - pre * y[1]))
-        for j in range(22, 0, -1):        # vowel_new.c:287-289
+        for j in range(order, 0, -1):     # vowel_new.c:287-289
             y[j] = y[j - 1]
     return np.array(out, dtype=np.int16)
 
@@ -72,3 +72,36 @@ def test_blended_pole_sets_are_stable_and_distinct():
         assert A[0] == 1.0 and np.abs(np.roots(A)).max() < 0.9999
         seen.add(tuple(A))
     assert len(seen) > 120
+
+
+def test_sets_of_any_order_up_to_max_order_equal_the_literal_recurrence():
+    """vs_lane.order 1..40 (MAX_ORDER, vowel_new.c:33): the oracle runs the reference's loop with that
+    Order; the literal Python statement is the check"""
+    orders = [1, 2, 5, 21, 22, 23, 24, 31, 39, 40]
+    lanes, fs, dur = configs.wide_order_lanes(orders)
+    rng = np.random.default_rng(9)
+    flow = rng.integers(-12000, 12000, size=(len(orders), 1500), dtype=np.int16)
+    got = po.filter(lanes, flow)
+    for l, order in enumerate(orders):
+        A = list(lanes[l].A)
+        assert np.abs(np.roots(A[:order + 1])).max() < 0.98
+        want = _filter_literal(A, float(lanes[l].gain), float(lanes[l].pre_emphasis), flow[l], order)
+        assert np.array_equal(got[l], want), order
+        assert np.abs(want.astype(int)).max() > 100    # not a dead filter
+
+
+def test_order_field_defaults_to_22_and_is_bounded():
+    lane, _ = vs.lane_from_cli(["-r", "16000", "-d", "1"], ["-v", "a"], 1)
+    A = vs.vowel_coefficients("a")
+    lane.vowel = 0
+    for j in range(23):
+        lane.A[j] = float(A[j])
+    o = C.c_int()
+    assert vs.load().vs_lane_order(C.byref(lane), C.byref(o)) == 0 and o.value == 22   # order 0 means 22
+    lane.order = 41
+    assert vs.load().vs_lane_order(C.byref(lane), C.byref(o)) == vs._ffi.VS_ERR_RANGE
+    assert vs.load().vs_lane_validate(C.byref(lane)) == vs._ffi.VS_ERR_RANGE
+    lane.order = 40
+    assert vs.load().vs_lane_validate(C.byref(lane)) == 0
+    lane.A[40] = float("nan")
+    assert vs.load().vs_lane_validate(C.byref(lane)) == vs._ffi.VS_ERR_RANGE

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("VS_LIB", "libvoicesynth.so
 
 VS_ORDER = 22
 VS_NCOEF = 23
+VS_MAX_ORDER = 40
+VS_MAX_NCOEF = 41
 
 VS_OK = 0
 VS_ERR_ARG = -1
@@ -58,7 +60,9 @@ class Lane(C.Structure):
         ("pre_emphasis", C.c_float),
         ("vowel", C.c_int32),
         ("out_snr", C.c_float),
-        ("A", C.c_double * VS_NCOEF),
+        ("A", C.c_double * VS_MAX_NCOEF),
+        ("order", C.c_int32),
+        ("reserved_", C.c_int32),
         ("out_seed", C.c_uint64),
     ]
 
@@ -151,6 +155,7 @@ SYMBOLS = {
     "vs_lane_defaults": (C.c_int, [_P(Lane)]),
     "vs_num_samples": (C.c_int, [C.c_int32, C.c_float, _P(C.c_uint64)]),
     "vs_vowel_coefficients": (C.c_int, [C.c_int, _P(C.c_double)]),
+    "vs_lane_order": (C.c_int, [_P(Lane), _P(C.c_int)]),
     "vs_vowel_name": (C.c_char_p, [C.c_int]),
     "vs_lane_validate": (C.c_int, [_P(Lane)]),
     "vs_strerror": (C.c_char_p, [C.c_int]),

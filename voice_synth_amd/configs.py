@@ -60,6 +60,40 @@ def blend_pole_sets(A1, A2, w):
     return A
 
 
+def random_pole_set(order, rng, rmax=0.97):
+    """A stable all-pole denominator of the given order (1..40): conjugate pole pairs at random
+    angles with radii in [0.6, rmax], one real pole when the order is odd.  Returns order + 1
+    coefficients, A[0] = 1."""
+    poles = []
+    for _ in range(order // 2):
+        z = rng.uniform(0.6, rmax) * np.exp(1j * rng.uniform(0.05, np.pi - 0.05))
+        poles += [z, np.conj(z)]
+    if order % 2:
+        poles.append(rng.uniform(-0.9, 0.9))
+    A = np.real(np.poly(poles)) if poles else np.array([1.0])
+    A[0] = 1.0
+    return A
+
+
+def wide_order_lanes(orders, lane0=0, seed0=1):
+    """Config-3-style utterances (16 kHz, 1 s, jitter + shimmer + noise) whose filters are explicit
+    coefficient sets of the given orders (vs_lane.order, 1..40): the MAX_ORDER row of SURVEY.md 8(f4)."""
+    from . import Lane, lane_from_cli  # noqa: F401  (late: this module is imported by the package)
+    rng = np.random.default_rng(40 + lane0)
+    fa = ["-r", "16000", "-d", "1", "-j", "1", "-s", "5.76", "-n", "20"]
+    arr = (Lane * len(orders))()
+    for i, order in enumerate(orders):
+        lane, dur = lane_from_cli(fa, ["-v", "a", "-g", "%.2f" % rng.uniform(1, 10), "-p", ["1", "0", "0.37", "0.9"][i % 4]],
+                                  seed0 + lane0 + i)
+        A = random_pole_set(int(order), rng)
+        lane.vowel = 0
+        lane.order = int(order)
+        for j in range(len(lane.A)):
+            lane.A[j] = float(A[j]) if j <= order else 0.0
+        arr[i] = lane
+    return arr, 16000, 1.0
+
+
 def config5_blended_lanes(n_lanes, lane0=0, seed0=1):
     """BASELINE config 5 with the FIRST reading of "randomised formant sets": per-utterance F0
     sweep as in config_specs(5, ...) and, per utterance, 23 coefficients of its own -- a convex

@@ -32,6 +32,7 @@
 
 extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
 extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
+extern "C" hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream);
 extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1,
                                        const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
                                        hipStream_t stream);
@@ -203,15 +204,31 @@ extern "C" int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev,
 /* ------------------------------------------------------------------------------------------
  * Host expansion of one lane (no device needed; exported for the CPU-side tests)
  * ---------------------------------------------------------------------------------------- */
+/* A[0..40] of the lane's filter: the table or the explicit set, zeros behind its order */
+static int vs_lane_taps(const vs_lane *lane, double *A)
+{
+  for (int j = 0; j < VS_MAX_NCOEF; j++) A[j] = 0.0;
+  if (lane->vowel != VS_VOWEL_CUSTOM) return vs_vowel_coefficients(lane->vowel, A);
+  int order = 0;
+  const int rc = vs_lane_order(lane, &order);
+  if (rc != VS_OK) return rc;
+  for (int j = 0; j <= order; j++) A[j] = lane->A[j];
+  return VS_OK;
+}
+
+static bool vs_lane_is_wide(const vs_lane *lane)
+{
+  return lane->vowel == VS_VOWEL_CUSTOM && lane->order > VS_ORDER;
+}
+
 extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 {
   int rc = vs_lane_validate(lane);
   if (rc != VS_OK) return rc;
-  double A[VS_NCOEF];
-  if (lane->vowel == VS_VOWEL_CUSTOM) memcpy(A, lane->A, sizeof(A));
-  else if ((rc = vs_vowel_coefficients(lane->vowel, A)) != VS_OK) return rc;
+  double A[VS_MAX_NCOEF];
+  if ((rc = vs_lane_taps(lane, A)) != VS_OK) return rc;
   memset(d, 0, sizeof(*d));
-  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j];
+  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j]; /* a wide set's first 22 taps: unused, the plan is wide */
   d->gain = (double)lane->gain;
   d->pre = (double)lane->pre_emphasis;
   d->jitter = lane->jitter;
@@ -313,14 +330,17 @@ static int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 {
   if (!(lane->pre_emphasis >= 0.0 && lane->pre_emphasis <= 1.0)) return VS_ERR_RANGE; /* vw:127 */
   if (!(lane->gain >= 1)) return VS_ERR_RANGE;                                        /* vw:132 */
-  double A[VS_NCOEF];
+  double A[VS_MAX_NCOEF];
   if (lane->vowel == VS_VOWEL_CUSTOM) {
-    for (int j = 0; j < VS_NCOEF; j++)
+    int order = 0;
+    const int rc = vs_lane_order(lane, &order);
+    if (rc != VS_OK) return rc;
+    for (int j = 0; j <= order; j++)
       if (!isfinite(lane->A[j])) return VS_ERR_RANGE;
     if (lane->A[0] != 1.0) return VS_ERR_RANGE;
-    memcpy(A, lane->A, sizeof(A));
-  } else {
-    int rc = vs_vowel_coefficients(lane->vowel, A);
+  }
+  {
+    const int rc = vs_lane_taps(lane, A);
     if (rc != VS_OK) return (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') ? VS_ERR_UNSUPPORTED : VS_ERR_RANGE;
   }
   if (lane->fs <= 0) return VS_ERR_RANGE;
@@ -420,6 +440,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   }
   bool pre1 = true;
   for (size_t l = 0; l < n_lanes; l++) pre1 = pre1 && (dl[l].pre == 1.0);
+  bool wide = false;
+  for (size_t l = 0; l < n_lanes && !wide; l++) wide = vs_lane_is_wide(&lanes[l]);
   if (!any_onoise) min_lframe = 0;
   if (any_onoise && min_lframe <= 0) return VS_ERR_UNSUPPORTED;
   /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its
@@ -458,7 +480,22 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   int wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_WS) wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
-  if (filter_only) wave_specialised = 0;
+  if (filter_only || wide) wave_specialised = 0;
+  /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
+  std::vector<double> awide;
+  if (wide) {
+    try {
+      awide.resize(n_lanes * (size_t)VS_WIDE_ORDER);
+    } catch (...) {
+      return VS_ERR_NOMEM;
+    }
+    double A[VS_MAX_NCOEF];
+    for (size_t l = 0; l < n_lanes; l++) {
+      const int rc = vs_lane_taps(&lanes[(size_t)dl[l].row], A);
+      if (rc != VS_OK) return rc;
+      for (int j = 1; j <= VS_WIDE_ORDER; j++) awide[l * VS_WIDE_ORDER + (size_t)(j - 1)] = A[j];
+    }
+  }
   unsigned wg_per_cu = (grid + cus - 1) / cus;
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
@@ -543,6 +580,10 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->ws_pair_bytes = ws_pair_bytes;
   p->filter_only = filter_only;
   p->pre1 = pre1 ? 1 : 0;
+  p->wide = wide ? 1 : 0;
+  p->d_awide = nullptr;
+  p->d_flow = nullptr;
+  p->flow_pitch = (n_samples + 7) & ~(size_t)7;
   p->tuning = tune;
 
   const auto t_host1 = std::chrono::steady_clock::now();
@@ -552,6 +593,11 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
+  if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, awide.size() * sizeof(double));
+  if (e == hipSuccess && wide && !filter_only)
+    e = hipMalloc((void **)&p->d_flow, n_lanes * p->flow_pitch * sizeof(int16_t));
+  if (e == hipSuccess && wide)
+    e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), ctx->stream);
   if (e == hipSuccess)
     e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
@@ -566,6 +612,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (p->d_costab) (void)hipFree(p->d_costab);
     if (p->d_err) (void)hipFree(p->d_err);
     if (p->d_opow) (void)hipFree(p->d_opow);
+    if (p->d_awide) (void)hipFree(p->d_awide);
+    if (p->d_flow) (void)hipFree(p->d_flow);
     delete p;
     return VS_ERR_HIP;
   }
@@ -590,6 +638,8 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_costab) (void)hipFree(p->d_costab);
   if (p->d_err) (void)hipFree(p->d_err);
   if (p->d_opow) (void)hipFree(p->d_opow);
+  if (p->d_awide) (void)hipFree(p->d_awide);
+  if (p->d_flow) (void)hipFree(p->d_flow);
   delete p;
 }
 
@@ -624,6 +674,11 @@ extern "C" int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_
 extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
 {
   if (!p || !buf || len == 0) return VS_ERR_ARG;
+  if (p->wide && kind != VS_KIND_SOURCE) {
+    snprintf(buf, len, "%svs_filter_wide_kernel<%d>", kind == VS_KIND_SYNTH ? "vs_synth_kernel<0, 1, false, false> + " : "",
+             p->ctx->arith);
+    return VS_OK;
+  }
   const int ws = p->wave_specialised && kind == VS_KIND_SYNTH && !p->d_opow;
   const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
   if (ws)
@@ -687,9 +742,29 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   if (kind == VS_KIND_FILTER) vec = vec && ((in_pitch & 1) == 0) && ((((uintptr_t)in_dev) & 3) == 0);
   a.vec_ok = vec;
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr,
-                               p->wave_specialised != 0 && a.opow == nullptr, p->pre1 != 0, &a, p->grid,
-                               p->lds_bytes, ctx->stream));
+  if (p->wide && kind != VS_KIND_SOURCE) {
+    /* 23..40 taps: un-fused.  The source kernel leaves the flow in HBM, the wide filter kernel
+     * reads it back (its input is the caller's for the filter-only kind). */
+    a.awide = p->d_awide;
+    if (kind == VS_KIND_SYNTH) {
+      VsKernelArgs src = a;
+      src.out = p->d_flow;
+      src.out_pitch = (long)p->flow_pitch;
+      src.opow = nullptr;
+      src.vec_ok = 1; /* rows of the plan's own buffer start 16-byte aligned */
+      VS_HIP(ctx, vs_launch_kernel(ctx->arith, VS_KIND_SOURCE, src.log != nullptr, false, false, &src, p->grid,
+                                   p->lds_bytes, ctx->stream));
+      a.in = p->d_flow;
+      a.in_pitch = (long)p->flow_pitch;
+      a.log = nullptr;
+      a.ncyc = nullptr;
+    }
+    VS_HIP(ctx, vs_launch_filter_wide(ctx->arith, &a, p->grid, ctx->stream));
+  } else {
+    VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr,
+                                 p->wave_specialised != 0 && a.opow == nullptr, p->pre1 != 0, &a, p->grid,
+                                 p->lds_bytes, ctx->stream));
+  }
   if (a.opow) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream)); /* vowel -n, second half */
   return VS_OK;
 }

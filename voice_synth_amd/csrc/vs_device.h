@@ -75,6 +75,10 @@ typedef struct VsKernelArgs {
   int fault;          /* VS_FAULT_* (tests only) */
   int ws_filter_prio; /* wave-specialised kernel: s_setprio of the filter wave (0 = leave at 0) */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
+  const double *awide; /* wide plans (a coefficient set of 23..40 taps): A[1..40] per lane record, zeros behind its order */
 } VsKernelArgs;
+
+#define VS_WIDE_ORDER 40 /* == VS_MAX_ORDER of voice_synth.h */
+#define VS_WIDE_SS 48    /* register window and super-step of the wide filter kernel (>= VS_WIDE_ORDER + 1, multiple of 8) */
 
 #endif

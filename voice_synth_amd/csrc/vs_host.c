@@ -71,6 +71,17 @@ int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples)
   return VS_OK;
 }
 
+/* taps of the lane's filter: 22 for the tables (vowel_new.c:172), vs_lane.order for an explicit set */
+int vs_lane_order(const vs_lane *lane, int *order)
+{
+  if (!lane || !order) return VS_ERR_ARG;
+  *order = VS_ORDER;
+  if (lane->vowel != VS_VOWEL_CUSTOM) return VS_OK;
+  if (lane->order < 0 || lane->order > VS_MAX_ORDER) return VS_ERR_RANGE; /* MAX_ORDER, vowel_new.c:33 */
+  if (lane->order > 0) *order = lane->order;
+  return VS_OK;
+}
+
 int vs_vowel_coefficients(int vowel, double *A)
 {
   if (!A) return VS_ERR_ARG;
@@ -118,7 +129,10 @@ int vs_lane_validate(const vs_lane *lane)
       return VS_ERR_RANGE;
     }
   } else {
-    for (int j = 0; j < VS_NCOEF; j++)
+    int order = 0;
+    const int rc = vs_lane_order(lane, &order);
+    if (rc != VS_OK) return rc;
+    for (int j = 0; j <= order; j++)
       if (!isfinite(lane->A[j])) return VS_ERR_RANGE;
     if (lane->A[0] != 1.0) return VS_ERR_RANGE;
   }

@@ -60,6 +60,10 @@ struct vs_plan {
   int ws_pair_bytes; /* LDS bytes of one pair */
   int filter_only;   /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
   int pre1;          /* every lane has pre_emphasis == 1.0 (the reference's default) */
+  int wide;          /* some lane carries a coefficient set of 23..40 taps: source kernel -> flow in HBM -> wide filter kernel */
+  double *d_awide;   /* wide plans: A[1..40] per lane record */
+  int16_t *d_flow;   /* wide plans that synthesise: the flow between the two kernels [n_lanes][flow_pitch] */
+  size_t flow_pitch;
   vs_tuning tuning;  /* the context's tuning when the plan was made */
   double host_ms;    /* host time of vs_plan_create: expansion, sorting, tables */
   double upload_ms;  /* ... and of the allocation + upload + wait that follows */

@@ -1321,6 +1321,123 @@ extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t 
 }
 
 /*
+ * Wide filter kernel: explicit coefficient sets of 23..40 taps (MAX_ORDER of vowel_new.c:33).
+ * The same recurrence as vs_superstep -- vowel_new.c:266-289 with a larger Order -- on a register
+ * window of 48 doubles and 40 coefficients per lane; the input is a flow row in HBM (the source
+ * kernel wrote it, or the caller supplied it), so this path is NOT fused.  Lanes of lower order
+ * carry zeros in the missing taps (acc - 0*y == acc).  One lane per thread, 64-thread workgroups.
+ */
+template <int ARITH>
+__global__ void __launch_bounds__(VS_WAVE) vs_filter_wide_kernel(VsKernelArgs args)
+{
+  const int lane = (int)threadIdx.x;
+  const long gl = (long)blockIdx.x * VS_WAVE + lane;
+  if (gl >= (long)args.n_lanes) return;
+  const VsDevLane *__restrict__ L = args.lanes + gl;
+  const int N = args.n_samples;
+  double a[VS_WIDE_ORDER + 1];
+  double y[VS_WIDE_SS];
+  a[0] = 1.0;
+  const double *__restrict__ aw = args.awide + gl * VS_WIDE_ORDER;
+#pragma unroll
+  for (int j = 1; j <= VS_WIDE_ORDER; ++j) a[j] = aw[j - 1];
+#pragma unroll
+  for (int j = 0; j < VS_WIDE_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
+  const double gain = L->gain;
+  const double pre = L->pre;
+  const long row = (long)L->row;
+  const int16_t *__restrict__ irow = args.in + row * args.in_pitch;
+  int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+  float *prow = args.opow ? args.opow + row * args.opow_pitch : nullptr;
+  const int Lframe = L->Lframe;
+  float fsum = 0.0f; /* vowel -n: running sum of y^2 of the current frame (vowel_new.c:303-307) */
+  int fpos = 0, fidx = 0;
+  const bool vec = args.vec_ok != 0;
+
+  for (int n = 0; n < N; n += VS_WIDE_SS) {
+    const bool whole = vec && (n + VS_WIDE_SS <= N);
+#pragma unroll
+    for (int g = 0; g < VS_WIDE_SS / 8; ++g) {
+      int xin[8];
+      if (whole) {
+        const vs_u32x4 v = *(const vs_u32x4 *)(irow + n + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xin[2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+          xin[2 * e + 1] = (int)(int16_t)(v[e] >> 16);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xin[k] = (n + 8 * g + k < N) ? (int)irow[n + 8 * g + k] : 0;
+      }
+      int outv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int t = 8 * g + k;
+        /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269) */
+        double acc = (double)xin[k] * gain;
+        const double y1 = y[(t + VS_WIDE_SS - 1) % VS_WIDE_SS];
+        if (ARITH == VS_ARITH_EXACT) {
+#pragma unroll
+          for (int j = 1; j <= VS_WIDE_ORDER; ++j) acc = acc - a[j] * y[(t + VS_WIDE_SS - j) % VS_WIDE_SS];
+        } else {
+          double p0 = acc, p1 = -(a[2] * y[(t + VS_WIDE_SS - 2) % VS_WIDE_SS]);
+#pragma unroll
+          for (int j = 3; j <= VS_WIDE_ORDER; ++j) {
+            const double yj = y[(t + VS_WIDE_SS - j) % VS_WIDE_SS];
+            if (j & 1) p0 = __builtin_fma(-a[j], yj, p0);
+            else p1 = __builtin_fma(-a[j], yj, p1);
+          }
+          acc = __builtin_fma(-a[1], y1, p0 + p1);
+        }
+        const double o = (ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc);
+        outv[k] = vs_round2int(o); /* vowel_new.c:284 */
+        y[t] = acc;                /* the window rotates by renaming, vowel_new.c:287-289 */
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (prow) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = n + 8 * g + k;
+          if (i < N) {
+            const float f = (float)outv[k];
+            fsum += f * f;
+            fpos += 1;
+            if (fpos == Lframe || i == N - 1) {
+              prow[fidx] = fsum;
+              fidx += 1;
+              fsum = 0.0f;
+              fpos = 0;
+            }
+          }
+        }
+      }
+      if (whole) {
+        vs_u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = ((uint32_t)outv[2 * e] & 0xFFFFu) | ((uint32_t)outv[2 * e + 1] << 16);
+        *(vs_u32x4 *)(orow + n + 8 * g) = v;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (n + 8 * g + k < N) orow[n + 8 * g + k] = (int16_t)outv[k];
+      }
+    }
+  }
+}
+
+extern "C" hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream)
+{
+  if (!args->awide || !args->in) return hipErrorInvalidValue;
+  if (arith == VS_ARITH_EXACT)
+    hipLaunchKernelGGL(vs_filter_wide_kernel<VS_ARITH_EXACT>, dim3(grid), dim3(VS_WAVE), 0, stream, *args);
+  else
+    hipLaunchKernelGGL(vs_filter_wide_kernel<VS_ARITH_FMA>, dim3(grid), dim3(VS_WAVE), 0, stream, *args);
+  return hipGetLastError();
+}
+
+/*
  * Device self-test (vs_ctx_selftest): the shortcuts this file takes instead of the reference's
  * library calls are checked against the straightforward form ON THE DEVICE.
  *   [0] vs_unit_of_draw(r) == (double)r / 2147483647.0 (the compiler's IEEE division) for ALL
