@@ -2,7 +2,7 @@
 every sample of every lane against the CPU oracle, default kernel choice and one-wave kernel,
 plus the source-only kind.  Needs the GPU; the oracle is the checker.
 
-    python tools/fuzz_soak.py [first_seed] [n_seeds] [lanes] [samples] [uniform|corners]
+    python tools/fuzz_soak.py [first_seed] [n_seeds] [lanes] [samples] [uniform|corners|sets22|sets40]
 
 "uniform" draws every option uniformly over its usual range (the generator of the test suite);
 "corners" draws every option from the END POINTS of the range the reference's parser accepts
@@ -34,7 +34,24 @@ def main():
     n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n_lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 12000
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
-    gen = _corner_lanes if (len(sys.argv) > 5 and sys.argv[5] == "corners") else _fuzz_lanes
+    mode = sys.argv[5] if len(sys.argv) > 5 else "uniform"
+    gen = _corner_lanes if mode == "corners" else _fuzz_lanes
+    if mode in ("sets22", "sets40"):
+        # a third of the lanes get an explicit coefficient set of random order: up to 22 taps (fused
+        # kernels) or up to MAX_ORDER 40 (the whole plan takes the wide path)
+        from voice_synth_amd import configs
+
+        def gen(seed, count, top=22 if mode == "sets22" else 40):
+            lanes = _fuzz_lanes(seed, count)
+            rng = np.random.default_rng(seed + 5)
+            for lane in lanes[::3]:
+                order = int(rng.integers(1, top + 1))
+                A = configs.random_pole_set(order, rng, rmax=0.95)
+                lane.vowel = 0
+                lane.order = order
+                for j in range(len(lane.A)):
+                    lane.A[j] = float(A[j]) if j <= order else 0.0
+            return lanes
     bad_total = 0
     lanes_total = 0
     t0 = time.time()
