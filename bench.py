@@ -105,12 +105,21 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
 
     host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(host_cores, po.max_threads()))
-    lanes_cal = 4 * cores
-    lanes, _ = vs.lanes_from_specs(specs_fn(lanes_cal))
-    t0 = time.perf_counter()
+    # warm-up (library load, start of the thread team), then calibrate on growing samples until one
+    # takes long enough to be a fair estimate
+    lanes, _ = vs.lanes_from_specs(specs_fn(cores))
     po.synth(lanes, n_samples, threads=cores)
-    t_cal = time.perf_counter() - t0
-    rate = lanes_cal * n_samples / t_cal
+    lanes_cal = 4 * cores
+    rate = 0.0
+    for _ in range(5):
+        lanes, _ = vs.lanes_from_specs(specs_fn(lanes_cal))
+        t0 = time.perf_counter()
+        po.synth(lanes, n_samples, threads=cores)
+        t_cal = time.perf_counter() - t0
+        rate = lanes_cal * n_samples / t_cal
+        if t_cal >= 0.3:
+            break
+        lanes_cal *= 8
     n_lanes = int(min(262144, max(lanes_cal, target_s * rate / n_samples)))
     n_lanes = (n_lanes // cores) * cores or cores
     lanes, _ = vs.lanes_from_specs(specs_fn(n_lanes))
