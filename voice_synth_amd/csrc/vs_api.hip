@@ -362,8 +362,9 @@ static int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 }
 
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                        int filter_only, vs_plan **out)
+                        int mode, vs_plan **out)
 {
+  const int filter_only = (mode & VS_PLAN_FILTER_ONLY) ? 1 : 0;
   if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
   *out = nullptr;
@@ -583,6 +584,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->wide = wide ? 1 : 0;
   p->d_awide = nullptr;
   p->d_flow = nullptr;
+  p->owns_flow = 0;
   p->flow_pitch = (n_samples + 7) & ~(size_t)7;
   p->tuning = tune;
 
@@ -594,8 +596,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
   if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, awide.size() * sizeof(double));
-  if (e == hipSuccess && wide && !filter_only)
-    e = hipMalloc((void **)&p->d_flow, n_lanes * p->flow_pitch * sizeof(int16_t));
+  if (e == hipSuccess && wide && !filter_only) {
+    const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
+    if (mode & VS_PLAN_POOL_SCRATCH) {
+      /* grows only with the first (largest) chunk of a pipeline, i.e. while nothing runs */
+      if (vs_pool_device(ctx, &ctx->pool.d_flow, &ctx->pool.d_flow_bytes, flow_bytes) != VS_OK) e = hipErrorOutOfMemory;
+      p->d_flow = (int16_t *)ctx->pool.d_flow;
+      p->owns_flow = 0;
+    } else {
+      e = hipMalloc((void **)&p->d_flow, flow_bytes);
+      p->owns_flow = 1;
+    }
+  }
   if (e == hipSuccess && wide)
     e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), ctx->stream);
@@ -613,7 +625,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (p->d_err) (void)hipFree(p->d_err);
     if (p->d_opow) (void)hipFree(p->d_opow);
     if (p->d_awide) (void)hipFree(p->d_awide);
-    if (p->d_flow) (void)hipFree(p->d_flow);
+    if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
     delete p;
     return VS_ERR_HIP;
   }
@@ -639,7 +651,7 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_err) (void)hipFree(p->d_err);
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_awide) (void)hipFree(p->d_awide);
-  if (p->d_flow) (void)hipFree(p->d_flow);
+  if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   delete p;
 }
 

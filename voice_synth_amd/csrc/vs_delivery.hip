@@ -83,6 +83,7 @@ void vs_pool_release(vs_ctx *ctx)
   }
   if (P.d_in) (void)hipFree(P.d_in);
   if (P.d_aux) (void)hipFree(P.d_aux);
+  if (P.d_flow) (void)hipFree(P.d_flow);
   for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
     if (P.staging[t]) (void)hipHostFree(P.staging[t]);
     if (P.copy_stream[t]) (void)hipStreamDestroy(P.copy_stream[t]);
@@ -246,7 +247,7 @@ static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   for (size_t row0 = 0; row0 < n_lanes && pipe.rc.load() == VS_OK; row0 += chunk, k ^= 1) {
     const size_t rows = std::min(chunk, n_lanes - row0);
     vs_plan *plan = nullptr;
-    rc = vs_plan_create_impl(ctx, lanes + row0, rows, n_samples, 0, &plan); /* host work, overlaps the device */
+    rc = vs_plan_create_impl(ctx, lanes + row0, rows, n_samples, VS_PLAN_POOL_SCRATCH, &plan); /* host work, overlaps the device */
     if (rc != VS_OK) break;
     plans.push_back(plan);
     {
@@ -337,7 +338,8 @@ static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lan
   if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   VsPool &P = ctx->pool;
   vs_plan *plan = nullptr;
-  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, kind == VS_KIND_FILTER, &plan);
+  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples,
+                               (kind == VS_KIND_FILTER ? VS_PLAN_FILTER_ONLY : 0) | VS_PLAN_POOL_SCRATCH, &plan);
   if (rc != VS_OK) return rc;
   const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
   const size_t bytes = n_lanes * pitch * sizeof(int16_t);

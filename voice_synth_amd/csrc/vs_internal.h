@@ -23,6 +23,8 @@ struct VsPool {
   size_t d_in_bytes;
   void *d_aux;              /* cycle log + cycle counts of vs_source */
   size_t d_aux_bytes;
+  void *d_flow;             /* wide plans made by the pipelines: the flow between source and wide filter kernel */
+  size_t d_flow_bytes;
   void *staging[VS_DELIVERY_THREADS]; /* pinned host memory, VS_STAGING_BYTES each */
   hipStream_t copy_stream[VS_DELIVERY_THREADS];
   hipStream_t compute_stream; /* compute chunks of vs_synth_rows when the caller set no stream */
@@ -64,6 +66,7 @@ struct vs_plan {
   double *d_awide;   /* wide plans: A[1..40] per lane record */
   int16_t *d_flow;   /* wide plans that synthesise: the flow between the two kernels [n_lanes][flow_pitch] */
   size_t flow_pitch;
+  int owns_flow;     /* d_flow was allocated for this plan (else: the context pool's, shared by the pipeline's chunk plans) */
   vs_tuning tuning;  /* the context's tuning when the plan was made */
   double host_ms;    /* host time of vs_plan_create: expansion, sorting, tables */
   double upload_ms;  /* ... and of the allocation + upload + wait that follows */
@@ -78,8 +81,12 @@ struct vs_plan {
     }                                            \
   } while (0)
 
+/* mode: VS_PLAN_* bits */
+#define VS_PLAN_FILTER_ONLY 1  /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
+#define VS_PLAN_POOL_SCRATCH 2 /* chunk plans of a pipeline: launches are serial on one stream, so a wide plan's
+                                  flow buffer is the context pool's instead of one allocation per chunk */
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                        int filter_only, vs_plan **out);
+                        int mode, vs_plan **out);
 /* grows *ptr (device memory) to at least bytes; VS_OK or VS_ERR_HIP */
 int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes);
 /* creates the delivery streams, events and pinned staging buffers on first use */

@@ -188,7 +188,7 @@ void shard_gather(ShardJob *j)
   for (size_t r0 = j->lo; r0 < j->hi && j->rc == VS_OK; r0 += chunk, k ^= 1) {
     const size_t rows = std::min(chunk, j->hi - r0);
     vs_plan *plan = nullptr;
-    j->rc = vs_plan_create_impl(ctx, j->lanes + r0, rows, j->n_samples, 0, &plan);
+    j->rc = vs_plan_create_impl(ctx, j->lanes + r0, rows, j->n_samples, VS_PLAN_POOL_SCRATCH, &plan);
     if (j->rc != VS_OK) break;
     plans.push_back(plan);
     int16_t *dst = j->root + r0 * j->root_pitch;
