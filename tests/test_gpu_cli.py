@@ -101,3 +101,21 @@ def test_vs_batch_rejects_what_the_reference_rejects(tmp_path):
     (tmp_path / "m.txt").write_text("-o a.wav -r 16000 | -v e\n")     # no 'e' table
     r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True)
     assert r.returncode == 1
+
+
+def test_random_command_lines_equal_the_reference_programs():
+    """tools/cli_fuzz.py on a small draw: both drop-in programs against the compiled reference
+    programs (oracle/_ref travels to the GPU box) on random command lines -- files byte for byte,
+    header included, and the complete stdout of both stages"""
+    import sys
+    from oracle import pyoracle as po
+    if not po.have_reference():
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cli_fuzz
+    old = sys.argv
+    sys.argv = ["cli_fuzz.py", "2026", "10"]
+    try:
+        assert cli_fuzz.main() == 0
+    finally:
+        sys.argv = old

@@ -1,0 +1,79 @@
+"""Drop-in check of the two programs over random command lines: voice_synth_amd/bin/flowgen_shimmer
+and voice_synth_amd/bin/vowel against oracle/_ref (the reference itself, compiled with the Philox
+random() shim) -- the .wav files byte for byte (72-byte LP64 header, which is what the reference
+build here writes) and the complete stdout of both programs.  Needs the GPU and oracle/_ref.
+
+    python tools/cli_fuzz.py [seed] [count]
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import voice_synth_amd as vs  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+from test_gpu_properties import _corner_lanes, _fuzz_lanes  # noqa: E402
+
+BIN = os.path.join(os.path.dirname(vs.__file__), "bin")
+
+
+def reference_defined(lane):
+    tmax = int(1.2 * int(np.float32(lane.fs) / np.float32(lane.F0))) + 2
+    return tmax <= int(lane.fs / lane.Fg * 2) and tmax <= 500
+
+
+def run_pair(dirname, exe_dir, fa, va, seed, ours):
+    env = dict(os.environ, VS_SEED=str(seed))
+    if ours:
+        env["VS_WAV_HEADER"] = "72"
+    else:
+        env["VS_DRAWLOG"] = os.path.join(dirname, "draws.txt")
+    fg = subprocess.run([os.path.join(exe_dir, "flowgen_shimmer"), "-o", "g.wav"] + fa, cwd=dirname, env=env,
+                        capture_output=True, timeout=120)
+    vw = subprocess.run([os.path.join(exe_dir, "vowel"), "-i", "g.wav", "-o", "o.wav"] + va, cwd=dirname, env=env,
+                        capture_output=True, timeout=120)
+    g = open(os.path.join(dirname, "g.wav"), "rb").read()
+    o = open(os.path.join(dirname, "o.wav"), "rb").read()
+    return fg, vw, g, o
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    if not po.have_reference():
+        sys.exit("oracle/_ref is not built")
+    bad = done = 0
+    for name, gen in (("uniform", _fuzz_lanes), ("corners", _corner_lanes)):
+        specs = []
+        lanes = gen(seed, 3 * count, specs=specs)
+        k = 0
+        for lane, (fa, va, s) in zip(lanes, specs):
+            if k >= count:
+                break
+            if not reference_defined(lane):
+                continue
+            k += 1
+            s &= (1 << 62) - 1
+            with tempfile.TemporaryDirectory(prefix="vsr") as dr, tempfile.TemporaryDirectory(prefix="vso") as do:
+                rfg, rvw, rg, ro = run_pair(dr, po.REF_DIR, fa, va, s, False)
+                ofg, ovw, og, oo = run_pair(do, BIN, fa, va, s, True)
+            same = (rg == og, ro == oo, rfg.stdout == ofg.stdout, rvw.stdout == ovw.stdout,
+                    rfg.returncode == ofg.returncode, rvw.returncode == ovw.returncode)
+            done += 1
+            if not all(same):
+                bad += 1
+                print("DIFFERENT (flow file, speech file, flowgen stdout, vowel stdout, rc, rc) = %s\n   %s | %s  seed %d"
+                      % (same, " ".join(fa), " ".join(va), s), flush=True)
+        print("%s: %d command lines compared" % (name, k), flush=True)
+    print("cli fuzz: %d command lines, %d with differences" % (done, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
