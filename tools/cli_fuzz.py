@@ -49,6 +49,7 @@ def main():
     if not po.have_reference():
         sys.exit("oracle/_ref is not built")
     bad = done = 0
+    batch = []
     for name, gen in (("uniform", _fuzz_lanes), ("corners", _corner_lanes)):
         specs = []
         lanes = gen(seed, 3 * count, specs=specs)
@@ -66,11 +67,32 @@ def main():
             same = (rg == og, ro == oo, rfg.stdout == ofg.stdout, rvw.stdout == ovw.stdout,
                     rfg.returncode == ofg.returncode, rvw.returncode == ovw.returncode)
             done += 1
+            batch.append((fa, va, s, ro))
             if not all(same):
                 bad += 1
                 print("DIFFERENT (flow file, speech file, flowgen stdout, vowel stdout, rc, rc) = %s\n   %s | %s  seed %d"
                       % (same, " ".join(fa), " ".join(va), s), flush=True)
         print("%s: %d command lines compared" % (name, k), flush=True)
+        # the same lines as ONE manifest through vs_batch (one launch per distinct sample count)
+        with tempfile.TemporaryDirectory(prefix="vsb") as db:
+            with open(os.path.join(db, "m.txt"), "w") as f:
+                for i, (fa, va, s, _) in enumerate(batch):
+                    f.write("seed=%d -o out%d.wav %s | %s\n" % (s, i, " ".join(fa), " ".join(va)))
+            r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=db, capture_output=True,
+                               env=dict(os.environ, VS_WAV_HEADER="72"), timeout=300)
+            nb = 0
+            for i, (fa, va, s, ro) in enumerate(batch):
+                try:
+                    got = open(os.path.join(db, "out%d.wav" % i), "rb").read()
+                except OSError:
+                    got = b""
+                if got != ro:
+                    nb += 1
+                    print("vs_batch output %d differs: %s | %s  seed %d" % (i, " ".join(fa), " ".join(va), s), flush=True)
+            print("%s: vs_batch rc %d, %d of %d files differ from the reference's  (%s)"
+                  % (name, r.returncode, nb, len(batch), r.stdout.decode(errors="replace").strip().splitlines()[-1] if r.stdout else ""), flush=True)
+            bad += nb + (1 if r.returncode else 0)
+        batch = []
     print("cli fuzz: %d command lines, %d with differences" % (done, bad))
     return 1 if bad else 0
 
