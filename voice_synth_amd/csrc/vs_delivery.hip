@@ -174,9 +174,13 @@ void worker(Pipe *p, int t)
       const int16_t *src = (const int16_t *)P.d_out[b.buf] + (b.row0 - b.buf_row0) * p->pitch;
       int16_t *dst = p->direct ? p->direct + b.row0 * p->n_samples : (int16_t *)P.staging[t];
       hipError_t e = hipStreamWaitEvent(P.copy_stream[t], P.done[b.buf], 0);
-      if (e == hipSuccess)
-        e = hipMemcpy2DAsync(dst, p->n_samples * 2, src, p->pitch * 2, p->n_samples * 2, b.rows,
-                             hipMemcpyDeviceToHost, P.copy_stream[t]);
+      if (e == hipSuccess) {
+        if (p->pitch == p->n_samples) /* rows are contiguous on both sides: one linear DMA */
+          e = hipMemcpyAsync(dst, src, b.rows * p->n_samples * 2, hipMemcpyDeviceToHost, P.copy_stream[t]);
+        else
+          e = hipMemcpy2DAsync(dst, p->n_samples * 2, src, p->pitch * 2, p->n_samples * 2, b.rows,
+                               hipMemcpyDeviceToHost, P.copy_stream[t]);
+      }
       if (e == hipSuccess) e = hipStreamSynchronize(P.copy_stream[t]);
       if (e != hipSuccess) {
         int ok = VS_OK;
