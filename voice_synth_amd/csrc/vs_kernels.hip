@@ -22,6 +22,11 @@
  *       the 24 int16 results leave as three 16-byte stores per lane at that lane's own n.
  *       The flow itself never reaches HBM.
  *
+ * Next to them: vs_out_noise_kernel (vowel -n, second half), vs_filter_wide_kernel (explicit
+ * coefficient sets of 23..40 taps: the same recurrence on a 48-sample window, reading a flow row
+ * from HBM -- the un-fused path), vs_selftest_kernel (the arithmetic shortcuts against their
+ * literal forms, on the device).
+ *
  * No MFMA: the path is a scalar recurrence per utterance, not a contraction.
  *
  * Arithmetic contract: this file is compiled with -ffp-contract=off.  VS_ARITH_EXACT keeps
