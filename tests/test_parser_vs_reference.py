@@ -83,8 +83,8 @@ def test_flowgen_argv_fuzz_against_the_compiled_reference():
             continue              # undefined behaviour in the reference (rate <= 0, cq = 0 with -n, ...): not compared
         n = vs.num_samples(lane.fs, cmd.dur)
         assert n == len(flow), (argv, n, len(flow))
-        if int(1.2 * int(np.float32(lane.fs) / np.float32(lane.F0))) + 2 > int(lane.fs / lane.Fg * 2):
-            continue              # a period may exceed the reference's malloc (fg:569): heap overrun there
+        if not _reference_defined(lane):
+            continue              # heap overrun (fg:569) or the uninitialised T4 (fg:114) in the reference
         want, _, _, _ = po.source_one(lane, n)
         assert np.array_equal(want, flow), argv
         accepted += 1
@@ -149,8 +149,14 @@ def test_vowel_argv_fuzz_against_the_compiled_reference():
 
 def _reference_defined(lane):
     """the reference's heap block x holds 2*fs/Fg samples (flowgen_shimmer.c:569) and w[] 500
-    (fg:115): a period beyond either is an overrun there"""
+    (fg:115): a period beyond either is an overrun there.  And its T4 is an uninitialised stack
+    variable (fg:114) that only a sample below the DC flow assigns: with noise on and a
+    DC flow of zero it is read before it is written -- what the compiled reference does then depends
+    on what the loader left on the stack (0 in this container, which is what the carry_t4_* goldens
+    record and what the engine defines)."""
     tmax = int(1.2 * int(np.float32(lane.fs) / np.float32(lane.F0))) + 2
+    if (lane.flags & _ffi.VS_FLAG_NOISE) and lane.DC <= 0:
+        return False
     return tmax <= int(lane.fs / lane.Fg * 2) and tmax <= 500
 
 
