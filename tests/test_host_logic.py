@@ -213,3 +213,20 @@ def test_cli_usage_text_equals_reference():
         ours = subprocess.run([os.path.join(os.path.dirname(vs.__file__), "bin", name)], capture_output=True)
         ref = subprocess.run([os.path.join(po.REF_DIR, name)], capture_output=True)
         assert ours.stdout == ref.stdout and ours.returncode == ref.returncode == 0
+
+
+def test_expand_lane_pads_a_low_order_set_with_zeros():
+    """an explicit set of fewer than 22 taps rides the order-22 kernels: taps behind its order are
+    zeros in the device record (acc - 0*y == acc)"""
+    from voice_synth_amd import configs
+    lanes, fs, dur = configs.wide_order_lanes([5, 22, 40])
+    d = _ffi.DevLane()
+    assert vs.load().vs_expand_lane(C.byref(lanes[0]), 0, C.byref(d)) == 0
+    assert [d.a[j] for j in range(5)] == [lanes[0].A[j + 1] for j in range(5)]
+    assert all(d.a[j] == 0.0 for j in range(5, 22))
+    assert vs.load().vs_expand_lane(C.byref(lanes[1]), 1, C.byref(d)) == 0
+    assert [d.a[j] for j in range(22)] == [lanes[1].A[j + 1] for j in range(22)]
+    # a wide set expands too (its first 22 taps; the plan carries all 40 separately)
+    assert vs.load().vs_expand_lane(C.byref(lanes[2]), 2, C.byref(d)) == 0
+    lanes[2].order = 41
+    assert vs.load().vs_expand_lane(C.byref(lanes[2]), 2, C.byref(d)) == _ffi.VS_ERR_RANGE
