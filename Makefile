@@ -44,7 +44,7 @@ $(CSRC)/vs_node.o: $(CSRC)/vs_node.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h
 $(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread
 
-clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
+clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
 
 $(BINDIR)/%: $(PKG)/cli/%.c $(PKG)/cli/cli_common.h $(LIB) | $(BINDIR)
 	$(CC) -O2 -ffp-contract=off -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lvoicesynth -lm -Wl,-rpath,'$$ORIGIN/../lib'
@@ -57,7 +57,7 @@ resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null $(CSRC)/vs_kernels.hip
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB) $(LIBDIR)/libvoicesynth_*.so $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch
+	rm -f $(CSRC)/*.o $(LIB) $(LIBDIR)/libvoicesynth_*.so $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
 	$(MAKE) -C oracle clean
 
 .PHONY: all clis oracle resources clean diag

@@ -119,3 +119,13 @@ def test_random_command_lines_equal_the_reference_programs():
         assert cli_fuzz.main() == 0
     finally:
         sys.argv = old
+
+
+def test_vs_bench_runs_from_plain_c():
+    """the C-only benchmark program: same workload description as bench.py, one JSON line"""
+    for extra in ([], ["--host"], ["--arith", "fma"]):
+        r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "4096", "--steps", "2", "--warmup", "1"] + extra,
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert d["utterances"] == 4096 and d["samples_per_utterance"] == 16000 and d["value"] > 100
