@@ -129,3 +129,9 @@ def test_vs_bench_runs_from_plain_c():
         assert r.returncode == 0, r.stderr
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert d["utterances"] == 4096 and d["samples_per_utterance"] == 16000 and d["value"] > 100
+    # the node entry over two logical shards of the one device
+    r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "2", "--warmup", "1", "--gpus", "2"],
+                       capture_output=True, timeout=300, env=dict(os.environ, VS_DEVICES="0,0"))
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["utterances_per_gpu"] == 3000 and d["value"] > 100

@@ -1,7 +1,7 @@
 /*
  * vs_bench -- the throughput of the fused source->filter path from plain C, no Python:
  *
- *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host]
+ *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G]
  *
  * Workload: BASELINE.json configs[2] -- N utterances (default 65536), vowel table "12467"[lane % 5],
  * 16 kHz, 1 s, jitter 1 %, shimmer 0.5 dB (-s 5.76), glottal noise 20 dB, lane key = 1 + lane --
@@ -9,6 +9,10 @@
  * exactly what voice_synth_amd/configs.py describes for bench.py.  Timed: K launches of one plan
  * into a device buffer (host clock around launch ... vs_plan_status, which waits), after W warm-up
  * launches.  --host times vs_synth() into a pinned host buffer instead (PCIe included).
+ * --gpus G times vs_node_synth_gather(): N utterances PER DEVICE (weak scaling, like bench.py),
+ * contiguous blocks over devices 0..G-1 (or the ordinals in VS_DEVICES, e.g. "0,0" = two logical
+ * shards of one device), every finished chunk copied into device 0's memory behind the synthesis
+ * of the next one; the line then also carries the slowest shard's compute time.
  * One line of JSON on stdout.  bench.py remains the driver's benchmark; this is the same
  * measurement for a maintainer who only has the C side.
  */
@@ -26,7 +30,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
   size_t n_lanes = 65536;
-  int steps = 20, warmup = 5, host = 0;
+  int steps = 20, warmup = 5, host = 0, gpus = 0;
   const char *arith = "exact";
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--lanes") && i + 1 < argc) n_lanes = (size_t)strtoull(argv[++i], NULL, 0);
@@ -34,12 +38,15 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "--warmup") && i + 1 < argc) warmup = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--arith") && i + 1 < argc) arith = argv[++i];
     else if (!strcmp(argv[i], "--host")) host = 1;
+    else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
     else {
-      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host]\n");
+      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G]\n");
       return 1;
     }
   }
-  if (n_lanes == 0 || steps < 1 || warmup < 0) return 1;
+  if (n_lanes == 0 || steps < 1 || warmup < 0 || gpus < 0 || gpus > 64) return 1;
+  const size_t per_gpu = n_lanes;
+  if (gpus > 0) n_lanes *= (size_t)gpus;
 
   /* the lane records, from the reference's command lines */
   char *fg_argv[] = {"flowgen_shimmer", "-o", "x.wav", "-r", "16000", "-d", "1", "-j", "1", "-s", "5.76", "-n", "20", NULL};
@@ -60,6 +67,44 @@ int main(int argc, char **argv)
     lanes[l].vowel = vc.vowel;
     lanes[l].seed = 1 + (uint64_t)l;
     lanes[l].out_seed = lanes[l].seed;
+  }
+
+  if (gpus > 0) {
+    int devs[64];
+    for (int d = 0; d < gpus; d++) devs[d] = d;
+    const char *list = getenv("VS_DEVICES");
+    for (int d = 0; list && *list && d < gpus; d++) {
+      devs[d] = atoi(list);
+      const char *c = strchr(list, ',');
+      list = c ? c + 1 : "";
+    }
+    vs_node *node = NULL;
+    int rc = vs_node_create(devs, gpus, &node);
+    vs_ctx *root = NULL;
+    void *out = NULL;
+    double total_ms = 0.0, shard_ms = 0.0, sum_ms = 0.0, worst_shard = 0.0;
+    if (rc == VS_OK && !strcmp(arith, "fma")) rc = vs_node_set_arith(node, VS_ARITH_FMA);
+    if (rc == VS_OK) rc = vs_node_ctx(node, 0, &root);
+    if (rc == VS_OK) rc = vs_dev_alloc(root, n_lanes * n_samples * sizeof(int16_t), &out);
+    for (int k = 0; rc == VS_OK && k < warmup + steps; k++) {
+      rc = vs_node_synth_gather(node, lanes, n_lanes, n_samples, (int16_t *)out, n_samples, VS_NODE_OVERLAP, &total_ms, &shard_ms);
+      if (k >= warmup) {
+        sum_ms += total_ms;
+        if (shard_ms > worst_shard) worst_shard = shard_ms;
+      }
+    }
+    if (rc != VS_OK) fprintf(stderr, "vs_bench: %s\n", vs_strerror(rc));
+    else
+      printf("{\"metric\": \"synthesised Msamples/s (whole node), PCM gathered into device %d\", \"value\": %.1f, "
+             "\"unit\": \"Msamples/s\", \"n_gpus\": %d, \"ms_per_step\": %.4f, \"slowest_shard_compute_ms\": %.4f, "
+             "\"steps\": %d, \"warmup\": %d, \"utterances_per_gpu\": %zu, \"samples_per_utterance\": %llu, "
+             "\"arith\": \"%s\", \"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
+             devs[0], (double)n_lanes * (double)n_samples * steps / (sum_ms * 1e-3) / 1e6, gpus, sum_ms / steps, worst_shard,
+             steps, warmup, per_gpu, (unsigned long long)n_samples, arith);
+    if (out) vs_dev_free(root, out);
+    vs_node_destroy(node);
+    free(lanes);
+    return rc == VS_OK ? 0 : 1;
   }
 
   vs_ctx *ctx = NULL;
