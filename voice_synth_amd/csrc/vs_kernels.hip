@@ -902,6 +902,71 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
   }
 }
 
+#ifdef VS_EXP_F32
+/*
+ * MEASUREMENT VARIANT, never shipped (make variant NAME=f32 DEFS=-DVS_EXP_F32; tools/f32_survey.py;
+ * profiles/r02_f32_mode_measured.txt): in this build VS_ARITH_FMA runs the filter super-step of the
+ * wave-specialised kernel in SINGLE precision with PACKED fused multiply-adds -- two taps per
+ * v_pk_fma_f32 -- which is the "fp32 / packed fast mode" of SURVEY.md 8(f4).  The window is 12
+ * register pairs {y[2q], y[2q+1]}; for an even sample index the 22 taps are 11 aligned pairs, for an
+ * odd one 10 pairs plus the newest and the oldest tap on their own.  ce[k] = {a[2k+2], a[2k+1]},
+ * co[k] = {a[2k+3], a[2k+2]}.  Measured: 1.22-1.24x the speed of VS_ARITH_FMA on BASELINE config 3,
+ * and an RMS error above the north star's 1e-5 for four of the reference's ten tables at its default
+ * gain (1.9e-5 for /i/) -- which is why the mode does not exist in the product.
+ */
+typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void vs_superstep_f32(const vs_f32x2 (&ce)[11], const vs_f32x2 (&co)[10], float a1, float a22,
+                                                 vs_f32x2 (&yp)[12], float gain, float pre, const int16_t *rp,
+                                                 int16_t *__restrict__ orow, int n, int N, bool vec_ok)
+{
+  int xin[VS_SS];
+#pragma unroll
+  for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+  int outv[VS_SS];
+#pragma unroll
+  for (int m = 0; m < 12; ++m) {
+    /* even sample t = 2m */
+    {
+      vs_f32x2 p = {(float)xin[2 * m] * gain, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 11; ++k) p = __builtin_elementwise_fma(-ce[k], yp[(m + 11 - k) % 12], p);
+      const float acc = p.x + p.y;
+      const float y1 = yp[(m + 11) % 12].y;
+      outv[2 * m] = vs_round2int((double)__builtin_fmaf(-pre, y1, acc));
+      yp[m].x = acc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    /* odd sample t = 2m + 1 */
+    {
+      vs_f32x2 p = {(float)xin[2 * m + 1] * gain, 0.0f};
+      const float y1 = yp[m].x;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) p = __builtin_elementwise_fma(-co[k], yp[(m + 11 - k) % 12], p);
+      float sc = __builtin_fmaf(-a22, yp[(m + 1) % 12].y, p.y);
+      sc = sc + p.x;
+      const float acc = __builtin_fmaf(-a1, y1, sc);
+      outv[2 * m + 1] = vs_round2int((double)__builtin_fmaf(-pre, y1, acc));
+      yp[m].y = acc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (vec_ok && (n + VS_SS <= N)) {
+#pragma unroll
+    for (int k = 0; k < VS_SS / 8; ++k) {
+      vs_u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
+      *(vs_u32x4 *)(orow + n + 8 * k) = v;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t)
+      if (n + t < N) orow[n + t] = (int16_t)outv[t];
+  }
+}
+#endif
+
 /* per-lane constants of the generator from the lane record */
 __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsCfg &c, VsGen &s)
 {
@@ -1206,6 +1271,16 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
     for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
     const double gain = L->gain;
     const double pre = L->pre;
+#ifdef VS_EXP_F32
+    vs_f32x2 ce[11], co[10], yp[12];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) ce[k] = (vs_f32x2){(float)L->a[2 * k + 1], (float)L->a[2 * k]};
+#pragma unroll
+    for (int k = 0; k < 10; ++k) co[k] = (vs_f32x2){(float)L->a[2 * k + 2], (float)L->a[2 * k + 1]};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) yp[k] = (vs_f32x2){0.0f, 0.0f};
+    const float a1f = (float)L->a[0], a22f = (float)L->a[21], gainf = (float)L->gain, pref = (float)L->pre;
+#endif
     int16_t *__restrict__ orow = args.out + row * args.out_pitch;
     const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
     int n = 0, rslot = 0, spins = 0;
@@ -1227,6 +1302,11 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
+#ifdef VS_EXP_F32
+          if (ARITH == VS_ARITH_FMA)
+            vs_superstep_f32(ce, co, a1f, a22f, yp, gainf, pref, ring + rslot * VS_WAVE + lane, orow, n, N, args.vec_ok != 0);
+          else
+#endif
           vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
                                                    orow, n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
