@@ -346,3 +346,18 @@ def test_config4_whole_batch_on_one_device(engine):
             assert np.array_equal(got, whole), shard
     finally:
         engine.dev_free(buf)
+
+
+def test_shape_fuzz_small_draw():
+    """tools/shape_fuzz.py on a small draw: random batch sizes, sample counts, entry points
+    (plan / vs_synth / rows callback / vs_source / vs_filter / node over logical shards) and kernels"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import shape_fuzz
+    old = sys.argv
+    sys.argv = ["shape_fuzz.py", "4242", "40"]
+    try:
+        assert shape_fuzz.main() == 0
+    finally:
+        sys.argv = old
