@@ -97,3 +97,13 @@ def test_trim_releases_and_the_context_keeps_working(engine):
     specs, fs, dur, _ = configs.config_specs(3, 100)
     lanes, d = vs.lanes_from_specs(specs)
     assert np.array_equal(engine.synth(lanes, 2000), po.synth(lanes, 2000))
+
+
+def test_a_row_longer_than_a_staging_block(engine):
+    """utterances of more than 8.4 M samples do not fit a 16 MiB staging block: vs_synth then lets
+    the runtime copy into the (pageable) destination directly instead of refusing"""
+    specs, fs, dur, _ = configs.config_specs(3, 2)
+    lanes, d = vs.lanes_from_specs(specs)
+    n = 8_500_001
+    got = engine.synth(lanes, n)
+    assert np.array_equal(got, po.synth(lanes, n))

@@ -326,7 +326,10 @@ extern "C" int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
                         int16_t *pcm)
 {
   if (!pcm) return VS_ERR_ARG;
-  if (vs_is_pinned(pcm)) /* DMA straight into the caller's buffer */
+  /* DMA straight into the caller's buffer when it is pinned -- and also when one row is longer than a
+   * staging block (utterances beyond 8.4 M samples): the runtime then stages the pageable
+   * destination itself, slower than our own staging but without a row-length limit */
+  if (vs_is_pinned(pcm) || n_samples * sizeof(int16_t) > VS_STAGING_BYTES)
     return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, nullptr, nullptr, pcm);
   CopyOut c = {pcm, n_samples};
   return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, copy_rows, &c, nullptr);
