@@ -266,9 +266,9 @@ int vs_plan_info(const vs_plan *plan, size_t *lds_bytes, size_t *n_workgroups,
  * chunks of the batch are still being synthesised (chunks of 16384 utterances, two device
  * buffers, four DMA workers with pinned staging buffers owned by the context).  If pcm is
  * PINNED host memory (vs_host_alloc, hipHostMalloc, hipHostRegister) the blocks are DMAed straight
- * into it; otherwise each block is copied from its staging buffer into pcm by its worker (rows
- * longer than a staging block -- more than 8 388 608 samples -- are copied into pcm by the
- * runtime's own pageable path instead). */
+ * into it; otherwise each block is copied from its staging buffer into pcm by its worker.  A
+ * staging buffer always holds at least one whole row: utterances of more than 8 388 608 samples
+ * make the context allocate larger ones (four of them, pinned). */
 int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *pcm);
 
 /* The same pipeline with the caller in the place of the memcpy: cb receives `rows` finished
@@ -276,8 +276,7 @@ int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples
  * buffer that is valid only during the call.  cb runs on the library's delivery threads, up to
  * four calls at a time for different blocks, in no particular order; every row is delivered
  * exactly once.  A non-zero return stops the pipeline with VS_ERR_IO.  (vs_batch writes its
- * .wav files from here: header + payload, fwrite after fwrite, as the reference does.)
- * A row must fit a staging block: n_samples <= 8 388 608, else VS_ERR_UNSUPPORTED. */
+ * .wav files from here: header + payload, fwrite after fwrite, as the reference does.) */
 typedef int (*vs_rows_cb)(void *user, size_t row0, size_t rows, const int16_t *pcm);
 int vs_synth_rows(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                   vs_rows_cb cb, void *user);

@@ -100,10 +100,19 @@ def test_trim_releases_and_the_context_keeps_working(engine):
 
 
 def test_a_row_longer_than_a_staging_block(engine):
-    """utterances of more than 8.4 M samples do not fit a 16 MiB staging block: vs_synth then lets
-    the runtime copy into the (pageable) destination directly instead of refusing"""
-    specs, fs, dur, _ = configs.config_specs(3, 2)
+    """utterances of more than 8.4 M samples do not fit a 16 MiB staging block: the context then
+    allocates staging buffers that hold a whole row (the callback contract is whole rows)"""
+    specs, fs, dur, _ = configs.config_specs(3, 3)
     lanes, d = vs.lanes_from_specs(specs)
     n = 8_500_001
-    got = engine.synth(lanes, n)
-    assert np.array_equal(got, po.synth(lanes, n))
+    want = po.synth(lanes, n)
+    assert np.array_equal(engine.synth(lanes, n), want)
+    got = np.zeros_like(want)
+
+    def sink(row0, block):
+        got[row0:row0 + len(block)] = block
+        return 0
+    engine.synth_rows(lanes, n, sink)
+    assert np.array_equal(got, want)
+    engine.trim()                     # give the 4 x 17 MiB of pinned memory back
+    assert np.array_equal(engine.synth(lanes[:2], 1000), want[:2, :1000])

@@ -57,15 +57,23 @@ int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes)
   return VS_OK;
 }
 
-int vs_pool_streams(vs_ctx *ctx)
+int vs_pool_streams(vs_ctx *ctx, size_t row_bytes)
 {
   VsPool &P = ctx->pool;
-  if (P.streams_ready) return VS_OK;
+  /* a staging buffer holds at least one whole row (callbacks receive whole rows) */
+  size_t want = VS_STAGING_BYTES;
+  if (row_bytes > want) want = (row_bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+  if (P.streams_ready && P.staging_bytes >= want) return VS_OK;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
     if (!P.copy_stream[t]) VS_HIP(ctx, hipStreamCreateWithFlags(&P.copy_stream[t], hipStreamNonBlocking));
-    if (!P.staging[t]) VS_HIP(ctx, hipHostMalloc(&P.staging[t], VS_STAGING_BYTES, hipHostMallocDefault));
+    if (P.staging[t] && P.staging_bytes < want) { /* only between pipelines */
+      VS_HIP(ctx, hipHostFree(P.staging[t]));
+      P.staging[t] = nullptr;
+    }
+    if (!P.staging[t]) VS_HIP(ctx, hipHostMalloc(&P.staging[t], want, hipHostMallocDefault));
   }
+  P.staging_bytes = want;
   if (!P.compute_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&P.compute_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++)
     if (!P.done[k]) VS_HIP(ctx, hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
@@ -204,8 +212,7 @@ static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
                               vs_rows_cb cb, void *user, int16_t *direct)
 {
   if (!ctx || !lanes || n_lanes == 0 || n_samples == 0 || (!cb && !direct)) return VS_ERR_ARG;
-  if (n_samples * sizeof(int16_t) > VS_STAGING_BYTES && !direct) return VS_ERR_UNSUPPORTED; /* one row per block at least */
-  int rc = vs_pool_streams(ctx);
+  int rc = vs_pool_streams(ctx, direct ? 0 : n_samples * sizeof(int16_t)); /* staging blocks hold whole rows */
   if (rc != VS_OK) return rc;
   VsPool &P = ctx->pool;
   const size_t pitch = (n_samples + 7) & ~(size_t)7; /* device rows start 16-byte aligned */
@@ -214,7 +221,7 @@ static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
     rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
     if (rc != VS_OK) return rc;
   }
-  size_t rows_per_block = VS_STAGING_BYTES / (n_samples * sizeof(int16_t));
+  size_t rows_per_block = P.staging_bytes / (n_samples * sizeof(int16_t));
   if (rows_per_block < 1) rows_per_block = 1;
   if (direct) rows_per_block = std::max<size_t>(rows_per_block, 1024); /* no staging limit: fewer, larger DMAs */
 
@@ -326,10 +333,7 @@ extern "C" int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
                         int16_t *pcm)
 {
   if (!pcm) return VS_ERR_ARG;
-  /* DMA straight into the caller's buffer when it is pinned -- and also when one row is longer than a
-   * staging block (utterances beyond 8.4 M samples): the runtime then stages the pageable
-   * destination itself, slower than our own staging but without a row-length limit */
-  if (vs_is_pinned(pcm) || n_samples * sizeof(int16_t) > VS_STAGING_BYTES)
+  if (vs_is_pinned(pcm)) /* DMA straight into the caller's buffer */
     return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, nullptr, nullptr, pcm);
   CopyOut c = {pcm, n_samples};
   return vs_synth_rows_impl(ctx, lanes, n_lanes, n_samples, copy_rows, &c, nullptr);

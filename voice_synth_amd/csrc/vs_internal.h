@@ -25,7 +25,8 @@ struct VsPool {
   size_t d_aux_bytes;
   void *d_flow;             /* wide plans made by the pipelines: the flow between source and wide filter kernel */
   size_t d_flow_bytes;
-  void *staging[VS_DELIVERY_THREADS]; /* pinned host memory, VS_STAGING_BYTES each */
+  void *staging[VS_DELIVERY_THREADS]; /* pinned host memory, staging_bytes each (VS_STAGING_BYTES, more when one row is longer) */
+  size_t staging_bytes;
   hipStream_t copy_stream[VS_DELIVERY_THREADS];
   hipStream_t compute_stream; /* compute chunks of vs_synth_rows when the caller set no stream */
   hipEvent_t done[2];       /* kernel of the chunk in d_out[k] has finished */
@@ -89,8 +90,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
                         int mode, vs_plan **out);
 /* grows *ptr (device memory) to at least bytes; VS_OK or VS_ERR_HIP */
 int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes);
-/* creates the delivery streams, events and pinned staging buffers on first use */
-int vs_pool_streams(vs_ctx *ctx);
+/* creates the delivery streams, events and pinned staging buffers (at least row_bytes each) on first use */
+int vs_pool_streams(vs_ctx *ctx, size_t row_bytes);
 void vs_pool_release(vs_ctx *ctx);
 
 #endif
