@@ -1,0 +1,8 @@
+set -e
+cd /tmp && rm -rf lb && mkdir lb && cd lb
+R=$GRAFT_REPO_ROOT
+echo "seed=5 -o ours.wav -r 16000 -d 600 -j 1 -s 5.76 -n 20 | -v 2 -g 3" > m.txt
+VS_WAV_HEADER=72 $R/voice_synth_amd/bin/vs_batch m.txt
+VS_SEED=5 VS_DRAWLOG=/tmp/lb/dl $R/oracle/_ref/flowgen_shimmer -o g.wav -r 16000 -d 600 -j 1 -s 5.76 -n 20 > /dev/null
+VS_SEED=5 VS_DRAWLOG=/tmp/lb/dl $R/oracle/_ref/vowel -i g.wav -o ref.wav -v 2 -g 3 > /dev/null
+ls -l ours.wav ref.wav; cmp ours.wav ref.wav && echo "10-minute utterance: vs_batch output equals the reference's, byte for byte"
