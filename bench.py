@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
                  every finished chunk travelling to rank 0 over RCCL while the next one is being
                  synthesised (voice_synth_amd/dist.py::PipelinedGather), timed end to end AFTER
                  the timed region; `value` itself leaves the PCM sharded.
+VS_BENCH_REHEARSAL=1|2 (tests only): all ranks share device 0 and talk over gloo, so that the N > 1
+control flow -- and with 2 also the pipelined gather leg, end to end on device tensors -- can be run on
+a one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
 The only use of oracle/ is inside cpu_baseline(): the CPU port and the compiled reference are
 timed there, and the port's rows are compared with the rows the GPU produced in the timed region --
 the whole batch (rms_vs_c_ref.rows_checked), since the CPU sample starts at lane 0 and outlasts it.
@@ -202,12 +205,23 @@ def main():
     from voice_synth_amd import configs
     from voice_synth_amd.dist import PipelinedGather, gather_pcm
 
+    # VS_BENCH_REHEARSAL=1 (tests only): all ranks share device 0 and talk over gloo -- the N > 1 control
+    # flow (sharded lane keys, barriers, max-over-ranks timing, rank 0's line) on a one-GPU box.  RCCL
+    # refuses two ranks on one device, so the gather leg is left out there.
+    rehearsal = os.environ.get("VS_BENCH_REHEARSAL") in ("1", "2")
+    if rehearsal:
+        local_rank = 0
+        if os.environ.get("VS_BENCH_REHEARSAL") == "1":
+            args.no_gather = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:  # launched by torch.distributed.run: one rank per GPU over RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload: per-GPU batch, lane keys from the global lane index ----
     full = {1: 1, 2: 1024, 3: 65536, 4: 262144 // 8, 5: 65536}[args.config]
@@ -434,7 +448,8 @@ def main():
             gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
                       "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
                       "ingress_GB/s": round(nbytes / g / 1e9, 1), "included_in_value": False,
-                      "transport": "RCCL send/recv, one grouped receive per chunk on the root (torch.distributed)"}
+                      "transport": "%s send/recv, one grouped receive per chunk on the root (torch.distributed)"
+                                   % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())}
             # the un-overlapped comparison: the same chunks, then one gather behind them
             sync_all()
             g0 = time.perf_counter()

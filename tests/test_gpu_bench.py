@@ -57,3 +57,22 @@ def test_bench_under_torch_distributed_run():
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     _check(lines[-1], 3)
+
+
+def test_bench_two_ranks_rehearsal_on_one_device():
+    """the N = 2 control flow of bench.py on a one-GPU box: two ranks share device 0 and talk over gloo
+    (VS_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device, so the gather leg is left out).  Each
+    rank synthesises its own block of the global batch; rank 0 prints the whole-job line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lanes", "4096", "--steps", "3",
+           "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600, env=dict(os.environ, VS_BENCH_REHEARSAL="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["utterances_per_gpu"] == 4096
+    # whole-job value = the units of both ranks over the slowest rank's time
+    assert abs(d["value"] - 2 * 4096 * 16000 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) / d["value"] < 0.01
+    assert "cpu_baseline" not in d              # rank 0 at N = 1 only
