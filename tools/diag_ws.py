@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import voice_synth_amd._ffi as ffi
-ffi.LIB_PATH = os.path.join(os.path.dirname(ffi.LIB_PATH), "libvoicesynth_diag.so")
+ffi.LIB_PATH = os.path.join(os.path.dirname(ffi.LIB_PATH), os.environ.get("VS_DIAG_LIB", "libvoicesynth_diag.so"))
 import voice_synth_amd as vs
 from voice_synth_amd import configs
 GN = ["jitter+shimmer", "rising", "Knew+falling", "closed", "noise", "bookkeeping", "sleep/poll", "loop ctl"]

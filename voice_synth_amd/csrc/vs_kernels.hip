@@ -48,7 +48,7 @@
 #define VS_PHILOX_W0 0x9E3779B9u
 #define VS_PHILOX_W1 0xBB67AE85u
 
-typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));   /* 16 bytes of a PCM row: rows are only 4-byte aligned */
 
 /* Diagnostic build only (-DVS_DIAG, tools/diag_bench.py): s_memtime stamps at phase boundaries,
  * summed per wavefront into args.diag.  The shipped library is built without it. */
@@ -72,6 +72,12 @@ __device__ __forceinline__ unsigned long long vs_stamp()
 #else
 #define VS_DIAG_ADD(dg, k)
 #endif
+
+/* {lo & 0xFFFF, hi << 16} in one instruction (V_PERM_B32: bytes 0,1 of lo, then bytes 0,1 of hi) */
+__device__ __forceinline__ uint32_t vs_pack16(int lo, int hi)
+{
+  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
 
 /* a ^ b ^ c in one instruction (gfx950 V_BITOP3_B32, truth table 0x96) */
 __device__ __forceinline__ uint32_t vs_xor3(uint32_t a, uint32_t b, uint32_t c)
@@ -214,6 +220,27 @@ __device__ __forceinline__ int vs_round2int(double x)
   return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
 }
 
+/*
+ * round2int() without its double rounding: ceil(x - 0.5), clamped.  This is round2int(x) for every
+ * double x EXCEPT the ones for which the reference's "x = x + 1" rounds up to an integer although
+ * x lies just below it -- the quirk set
+ *     Q1 = [-2^-54, -0)                    (x + 1 rounds to 1.0: the reference returns 1, not 0)
+ *     Q2 = { 2^m - 2^(m-53), m = 0..51 }   (mantissa all ones: x + 1 is a tie that rounds up)
+ * (for |x| >= 1 both x - 0.5 and x + 1 are exact or round without reaching an integer; the interval
+ * (-1, 1) is gone through case by case in tests/test_round2int.py and on the device by
+ * vs_ctx_selftest [3]).  Every member of Q1 has a high word in [0x80000000, 0xBC900000] and every
+ * member of Q2 a low word of 0xFFFFFFFF, so a super-step keeps the signed minimum of the high words
+ * and the unsigned maximum of the low words of its 24 arguments (one V_MIN3 / V_MAX3 per two
+ * samples) and, when either hits, rounds that super-step again with vs_round2int() -- outputs are
+ * not fed back, so nothing else has to be redone.  Three fp64 instructions per sample instead of five.
+ */
+__device__ __forceinline__ int vs_round2int_half_down(double x)
+{
+  const int v = (int)ceil(x - 0.5);
+  return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
+}
+#define VS_R2I_Q1_HI ((int)0xBC900000) /* high word of -2^-54, as a signed integer */
+
 /* (int)sqrt(v) of the reference (flowgen_shimmer.c:382) for a float-valued v >= 0: the
  * device sqrt only seeds an exact integer search, so its last-bit rounding cannot matter */
 __device__ __forceinline__ int vs_isqrt_floor(double v)
@@ -225,6 +252,20 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
   return s;
 }
 
+/*
+ * LDS ring layout: int16 ring[C + 8][64] -- slot-major, lane l owns column l, one slot of all 64
+ * lanes is 128 contiguous bytes, so a ds_write_b16 / ds_read_i16 of a wavefront touches every bank
+ * once (two lanes per 4-byte bank, same dword).  Slots [C, C + 8) are the trash rows: where lanes that
+ * must not emit send their 8-sample trips.  (A lane-major layout -- 16 contiguous bytes per lane and
+ * 8 slots -- lets the filter side read 8 samples per LDS instruction, but single-sample writes then
+ * hit every bank eight times over and the generator alone runs 15 % longer; measured in round 3,
+ * profiles/r03_kernel_experiments.txt.)
+ */
+#define VS_RING_STEP (VS_WAVE * 2)    /* bytes from a lane's slot s to its slot s + 1 */
+
+/* int16 index of ring slot `slot` (0 <= slot < C + 8; slots [C, C + 8) are the trash rows) */
+__device__ __forceinline__ int vs_ring_idx(int slot, int lane) { return slot * VS_WAVE + lane; }
+
 /* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
  * at most once (wpos < C, i < C + VS_TRASH_ROWS). */
 __device__ __forceinline__ int vs_ring_at(int wpos, int C, int i, int lane)
@@ -232,14 +273,14 @@ __device__ __forceinline__ int vs_ring_at(int wpos, int C, int i, int lane)
   /* slot = (wpos + i) mod C for wpos + i < 2C, as min(s, s - C) on unsigned (two instructions) */
   const unsigned sl = (unsigned)(wpos + i);
   const unsigned wr = sl - (unsigned)C;
-  return (int)((sl < wr) ? sl : wr) * VS_WAVE + lane;
+  return vs_ring_idx((int)((sl < wr) ? sl : wr), lane);
 }
 
-/* Eight consecutive ring slots of a lane, starting at cycle sample i0: the run wraps at most once,
- * after kw slots.  A sample costs one compare, one select and the store (the slot offset w*128
- * sits in the store's immediate). */
+/* Eight consecutive ring slots of a lane that start ANYWHERE (the noise trips follow the Philox
+ * blocks, not the ring): the run wraps at most once, after kw slots.  A sample costs one compare,
+ * one select and the store (the slot offset W*128 sits in the store's immediate). */
 struct VsRun8 {
-  char *A, *B; /* LDS address of slot i0 before / after the wrap */
+  char *A, *B; /* LDS address of slot 0 of the run before / after the wrap */
   int kw;      /* slots before the wrap (>= 8: none in this run) */
 };
 __device__ __forceinline__ VsRun8 vs_run8(int16_t *ring, int wpos, int C, int i0, int lane)
@@ -249,16 +290,26 @@ __device__ __forceinline__ VsRun8 vs_run8(int16_t *ring, int wpos, int C, int i0
   const unsigned a0 = (sl < wr) ? sl : wr;
   VsRun8 r;
   r.kw = C - (int)a0;
-  r.A = (char *)ring + (a0 * (unsigned)(VS_WAVE * 2) + (unsigned)(2 * lane));
-  r.B = r.A - (unsigned)C * (unsigned)(VS_WAVE * 2);
+  r.A = (char *)ring + (a0 * (unsigned)VS_RING_STEP + (unsigned)(2 * lane));
+  r.B = r.A - (unsigned)C * (unsigned)VS_RING_STEP;
   return r;
+}
+/* the run of the next 8 slots */
+__device__ __forceinline__ void vs_run8_advance(VsRun8 &r, int C)
+{
+  r.kw -= 8;
+  r.A += 8 * VS_RING_STEP;
+  const bool wrapped = r.kw <= 0; /* the whole of the next run lies behind the wrap */
+  r.A = wrapped ? r.B + 8 * VS_RING_STEP : r.A;
+  r.kw = wrapped ? r.kw + C : r.kw;
+  r.B = r.A - (unsigned)C * (unsigned)VS_RING_STEP;
 }
 /* all eight stores of a lane go to the trash rows [C, C + 8) */
 __device__ __forceinline__ VsRun8 vs_run8_trash(int16_t *ring, int C, int lane)
 {
   VsRun8 r;
   r.kw = 8;
-  r.A = (char *)ring + ((unsigned)C * (unsigned)(VS_WAVE * 2) + (unsigned)(2 * lane));
+  r.A = (char *)ring + ((unsigned)C * (unsigned)VS_RING_STEP + (unsigned)(2 * lane));
   r.B = r.A;
   return r;
 }
@@ -274,11 +325,12 @@ __device__ __forceinline__ VsRun8 vs_run8_or_trash(bool emit, int16_t *ring, int
   r.B = emit ? a.B : t.B;
   return r;
 }
+
 template <int W>
 __device__ __forceinline__ void vs_run8_store(const VsRun8 &r, int v)
 {
   char *p = (W < r.kw) ? r.A : r.B;
-  *(int16_t *)(p + W * VS_WAVE * 2) = (int16_t)v;
+  *(int16_t *)(p + W * VS_RING_STEP) = (int16_t)v;
 }
 /* the same, but to the trash rows (address trashA of row C) unless ok */
 template <int W>
@@ -286,7 +338,7 @@ __device__ __forceinline__ void vs_run8_store_if(const VsRun8 &r, char *trashA, 
 {
   char *p = (W < r.kw) ? r.A : r.B;
   p = ok ? p : trashA;
-  *(int16_t *)(p + W * VS_WAVE * 2) = (int16_t)v;
+  *(int16_t *)(p + W * VS_RING_STEP) = (int16_t)v;
 }
 __device__ __forceinline__ void vs_run8_store_all(const VsRun8 &r, const int (&x)[8])
 {
@@ -352,6 +404,17 @@ __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDia
 /* psum + (float)x*(float)x of flowgen_shimmer.c:376 for an integer sample |x| <= 32767: the
  * square is exact in 32-bit integers and its conversion rounds exactly as the float product. */
 __device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
+
+/* Publishing progress through LDS: the LDS performs the operations of ONE wavefront in the order
+ * they were issued, so a progress word stored after the data is seen after the data by whoever
+ * reads the word first and the data second -- no wait for the data stores to come back is needed,
+ * only the compiler must not move the accesses across each other (a fence with workgroup scope
+ * would add an s_waitcnt lgkmcnt(0), a full LDS round trip, to every noise trip). */
+#ifdef VS_EXP_HWFENCE
+#define VS_LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#else
+#define VS_LDS_RELEASE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
+#endif
 
 #ifndef VS_PUB_EVERY
 #define VS_PUB_EVERY 1 /* wave-specialised kernel: the generator publishes its noise progress every N-th trip (power of two) */
@@ -597,7 +660,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         run = run && !brk;
         const bool keep = act && !brk;
         psum = keep ? (psum + xfv[k] * xfv[k]) : psum;
-        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, C, i, lane) : (C * VS_WAVE + lane)] =
+        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, C, i, lane) : vs_ring_idx(C, lane)] =
             (int16_t)xsv[k];
       }
     }
@@ -608,7 +671,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
     /* wave-specialised kernel: the open phase [0, T3) is in the ring -- let the filter wave have
      * it while the closed phase is still being written (the LDS keeps this store behind the
      * ring writes above).  Not when noise will still be added to [0, T4) below. */
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    VS_LDS_RELEASE();
     __hip_atomic_store(gpub_lane, s.g + ((T3 < lim) ? T3 : lim), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -657,27 +720,32 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
       const VsNoiseK nk = vs_noise_consts(NDW, c.dcs);
       int q0 = (int)(4u * bfirst - d0);
       uint32_t b = bfirst;
+      /* The trips follow the Philox blocks, not the ring: a trip's 8 slots start anywhere and may
+       * wrap (compare + select per sample); the run itself moves on by 8 slots per trip instead of
+       * being worked out from the cycle's start every time.  T3 + q0 >= 1: VS_DF_FAST lanes have
+       * T2 >= 4. */
+      VsRun8 run = vs_run8(ring, s.wpos, C, T3 + q0, lane);
+      char *const trashA = vs_run8_trash(ring, C, lane).A;
       {
         uint32_t o[8];
         vs_philox2(b, rk, o);
         int xv[8];
 #pragma unroll
         for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-        /* T3 + q0 >= 1: VS_DF_FAST lanes have T2 >= 4.  Words in front of the cycle's first
-         * noise draw (q0 + w < 0) go to the trash rows. */
-        const VsRun8 r8 = vs_run8_or_trash(m > 0, ring, s.wpos, C, T3 + q0, lane);
-        char *trashA = vs_run8_trash(ring, C, lane).A;
-        vs_run8_store_if<0>(r8, trashA, q0 + 0 >= 0, xv[0]);
-        vs_run8_store_if<1>(r8, trashA, q0 + 1 >= 0, xv[1]);
-        vs_run8_store_if<2>(r8, trashA, q0 + 2 >= 0, xv[2]);
-        vs_run8_store<3>(r8, xv[3]); vs_run8_store<4>(r8, xv[4]);
-        vs_run8_store<5>(r8, xv[5]); vs_run8_store<6>(r8, xv[6]);
-        vs_run8_store<7>(r8, xv[7]);
+        /* words in front of the cycle's first noise draw (q0 + w < 0) go to the trash rows */
+        char *A = (m > 0) ? run.A : trashA, *B = (m > 0) ? run.B : trashA;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          char *pw = (w < run.kw) ? A : B;
+          if (w < 3) pw = (q0 + w >= 0) ? pw : trashA;
+          *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
+        }
         q0 += 8;
         b += 2u;
+        vs_run8_advance(run, C);
         if (PUB) {
           const int done = (q0 < m) ? q0 : m;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          VS_LDS_RELEASE();
           __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -689,14 +757,17 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         int xv[8];
 #pragma unroll
         for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-        const VsRun8 r8 = vs_run8_or_trash(q0 < m, ring, s.wpos, C, T3 + q0, lane);
-        vs_run8_store_all(r8, xv);
+        /* a lane that is done sends the trip to the trash rows */
+        char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) *(int16_t *)(((w < run.kw) ? A : B) + w * VS_RING_STEP) = (int16_t)xv[w];
         q0 += 8;
         b += 2u;
+        vs_run8_advance(run, C);
         ++trip;
         if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
           const int done = (q0 < m) ? q0 : m;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          VS_LDS_RELEASE();
           __hip_atomic_store(gpub_lane, s.g + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
@@ -738,12 +809,12 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
           const bool ok = (unsigned)q < (unsigned)mlim;
           const unsigned sl = (unsigned)(slot0 + q), wr = sl - (unsigned)C; /* (slot0 + q) mod C */
           const int slot = (int)((sl < wr) ? sl : wr);
-          ring[(ok ? slot : C) * VS_WAVE + lane] = (int16_t)xv;
+          ring[vs_ring_idx(ok ? slot : C, lane)] = (int16_t)xv;
         }
         q0 += 8;
         if (PUB) {
           const int done = (q0 < mlim) ? q0 : mlim; /* noise samples [T3, T3 + done) are written */
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          VS_LDS_RELEASE();
           __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -803,36 +874,42 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
   VS_DIAG_ADD(dg, 5)
 }
 
+/* the 8 samples of one granule / of 16 bytes of a PCM row, as integers */
+__device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
+{
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+    x[2 * e + 1] = (int)v[e] >> 16;
+  }
+}
+
 /*
  * One filter super-step of one lane: 24 samples of vowel_new.c:266-289 starting at the lane's
  * own position n.  x comes from the lane's ring column (rp = &ring[rslot][lane], never wraps
  * inside a super-step because ring_slots is a multiple of VS_SS and rslot advances by VS_SS
- * from 0) or, for VS_KIND_FILTER, from HBM.  The 24 int16 results leave as three 16-byte
- * stores.  y[] is the rotating window of the last 24 outputs in double (y[t] = y at n+t-24
- * on entry, = y at n+t on exit).
+ * from 0) or, for VS_KIND_FILTER, from HBM.  The 24 int16 results leave as three
+ * 16-byte stores (store_ok: lanes beyond the batch run along in the all-lanes loop of the
+ * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
+ * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
  */
 template <int ARITH, int KIND, bool PRE1 = false>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
                                              int16_t *__restrict__ orow, int n, int N, bool vec_ok,
-                                             int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8])
+                                             int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8],
+                                             bool store_ok = true)
 {
+  const bool whole = vec_ok && (n + VS_SS <= N);
   int xin[VS_SS];
   if (KIND == VS_KIND_FILTER) {
-    if (vec_ok && (n + VS_SS <= N)) {
+    if (whole) {
       /* xnext[] holds this super-step's 48 bytes, loaded one super-step ago; the loads for the
-       * next one are issued now and complete behind the ~1400 instructions below (with one
+       * next one are issued now and complete behind the ~1300 instructions below (with one
        * wave per SIMD nothing else hides an HBM round trip) */
 #pragma unroll
-      for (int k = 0; k < VS_SS / 8; ++k) {
-        const vs_u32x4 v = xnext[k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xin[8 * k + 2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
-          xin[8 * k + 2 * e + 1] = (int)(int16_t)(v[e] >> 16);
-        }
-      }
+      for (int k = 0; k < VS_SS / 8; ++k) vs_unpack8(xnext[k], &xin[8 * k]);
       if (n + 2 * VS_SS <= N) {
 #pragma unroll
         for (int k = 0; k < VS_SS / 8; ++k) xnext[k] = *(const vs_u32x4 *)(irow + n + VS_SS + 8 * k);
@@ -848,8 +925,11 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
 
   if (KIND == VS_KIND_SOURCE) {
 #pragma unroll
-    for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t];
+    for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t]; /* the flow itself */
   } else {
+    const double ym1 = y[VS_SS - 1]; /* y[n-1]: only the quirk path below needs it once y[23] is replaced */
+    int qhi = 0x7FFFFFFF;            /* signed minimum of the high words of the rounded values */
+    uint32_t qlo = 0u;               /* unsigned maximum of their low words */
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t) {
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
@@ -878,94 +958,48 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
        * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
       const double o = PRE1 ? (acc - y1)
                             : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
-      outv[t] = vs_round2int(o);
+      outv[t] = vs_round2int_half_down(o);
+      {
+        const int ohi = __double2hiint(o);
+        const uint32_t olo = (uint32_t)__double2loint(o);
+        qhi = (ohi < qhi) ? ohi : qhi;
+        qlo = (olo > qlo) ? olo : qlo;
+      }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu))) {
+      /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
+       * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again, literally */
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) {
+        const double y1 = (t == 0) ? ym1 : y[t - 1];
+        const double o = PRE1 ? (y[t] - y1)
+                              : ((ARITH == VS_ARITH_EXACT) ? (y[t] - pre * y1) : __builtin_fma(-pre, y1, y[t]));
+        outv[t] = vs_round2int(o);
+      }
+    }
   }
 
-  if (vec_ok && (n + VS_SS <= N)) {
+  if (whole) {
+    vs_u32x4 v[VS_SS / 8];
 #pragma unroll
     for (int k = 0; k < VS_SS / 8; ++k) {
-      vs_u32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
-      *(vs_u32x4 *)(orow + n + 8 * k) = v;
+      for (int e = 0; e < 4; ++e) v[k][e] = vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+    }
+    if (store_ok) {
+#pragma unroll
+      for (int k = 0; k < VS_SS / 8; ++k) *(vs_u32x4 *)(orow + n + 8 * k) = v[k];
     }
   } else {
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t)
-      if (n + t < N) orow[n + t] = (int16_t)outv[t];
+      if (store_ok && (n + t < N)) orow[n + t] = (int16_t)outv[t];
   }
 }
-
-#ifdef VS_EXP_F32
-/*
- * MEASUREMENT VARIANT, never shipped (make variant NAME=f32 DEFS=-DVS_EXP_F32; tools/f32_survey.py;
- * profiles/r02_f32_mode_measured.txt): in this build VS_ARITH_FMA runs the filter super-step of the
- * wave-specialised kernel in SINGLE precision with PACKED fused multiply-adds -- two taps per
- * v_pk_fma_f32 -- which is the "fp32 / packed fast mode" of SURVEY.md 8(f4).  The window is 12
- * register pairs {y[2q], y[2q+1]}; for an even sample index the 22 taps are 11 aligned pairs, for an
- * odd one 10 pairs plus the newest and the oldest tap on their own.  ce[k] = {a[2k+2], a[2k+1]},
- * co[k] = {a[2k+3], a[2k+2]}.  Measured: 1.22-1.24x the speed of VS_ARITH_FMA on BASELINE config 3,
- * and an RMS error above the north star's 1e-5 for four of the reference's ten tables at its default
- * gain (1.9e-5 for /i/) -- which is why the mode does not exist in the product.
- */
-typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void vs_superstep_f32(const vs_f32x2 (&ce)[11], const vs_f32x2 (&co)[10], float a1, float a22,
-                                                 vs_f32x2 (&yp)[12], float gain, float pre, const int16_t *rp,
-                                                 int16_t *__restrict__ orow, int n, int N, bool vec_ok)
-{
-  int xin[VS_SS];
-#pragma unroll
-  for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
-  int outv[VS_SS];
-#pragma unroll
-  for (int m = 0; m < 12; ++m) {
-    /* even sample t = 2m */
-    {
-      vs_f32x2 p = {(float)xin[2 * m] * gain, 0.0f};
-#pragma unroll
-      for (int k = 0; k < 11; ++k) p = __builtin_elementwise_fma(-ce[k], yp[(m + 11 - k) % 12], p);
-      const float acc = p.x + p.y;
-      const float y1 = yp[(m + 11) % 12].y;
-      outv[2 * m] = vs_round2int((double)__builtin_fmaf(-pre, y1, acc));
-      yp[m].x = acc;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    /* odd sample t = 2m + 1 */
-    {
-      vs_f32x2 p = {(float)xin[2 * m + 1] * gain, 0.0f};
-      const float y1 = yp[m].x;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) p = __builtin_elementwise_fma(-co[k], yp[(m + 11 - k) % 12], p);
-      float sc = __builtin_fmaf(-a22, yp[(m + 1) % 12].y, p.y);
-      sc = sc + p.x;
-      const float acc = __builtin_fmaf(-a1, y1, sc);
-      outv[2 * m + 1] = vs_round2int((double)__builtin_fmaf(-pre, y1, acc));
-      yp[m].y = acc;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  if (vec_ok && (n + VS_SS <= N)) {
-#pragma unroll
-    for (int k = 0; k < VS_SS / 8; ++k) {
-      vs_u32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = ((uint32_t)outv[8 * k + 2 * e] & 0xFFFFu) | ((uint32_t)outv[8 * k + 2 * e + 1] << 16);
-      *(vs_u32x4 *)(orow + n + 8 * k) = v;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < VS_SS; ++t)
-      if (n + t < N) orow[n + t] = (int16_t)outv[t];
-  }
-}
-#endif
 
 /* per-lane constants of the generator from the lane record */
 __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsCfg &c, VsGen &s)
@@ -1039,7 +1073,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
   VsCfg c;
   VsGen s;
-  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE); /* rows [C, C+8) are the trash rows */
+  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE); /* slots [C, C+8) are the trash granule */
   if (KIND != VS_KIND_FILTER) {
     vs_load_cfg(L, c, s);
     vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
@@ -1206,6 +1240,12 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
   else npub[lane] = 0;
   __syncthreads();
 
+#ifdef VS_EXP_G_ONLY
+  if (wave != 0) return;
+#endif
+#ifdef VS_EXP_F_ONLY
+  if (wave == 0) return;
+#endif
   if (wave == 0) {
     /* ------------------------------- generator wave ------------------------------- */
     VsCfg c;
@@ -1227,14 +1267,18 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
       const bool need = valid && (s.g < N);
       if (!__any(need)) break;
       if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
+#ifdef VS_EXP_G_ONLY
+      const int n_seen = s.g; /* timing experiment: the generator alone, never short of room */
+#else
       const int n_seen = __hip_atomic_load(&npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
       const bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
       const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
       const int n_need = __builtin_popcountll(__ballot(need));
       const int n_want = __builtin_popcountll(__ballot(want));
       if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
         if (want) vs_cycle_emit<false, true>(c, s, ring, C, lane, N, ltab, nullptr, 0, dg, &gpub[lane]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        VS_LDS_RELEASE();
         __hip_atomic_store(&gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         spins = 0;
       } else {
@@ -1271,16 +1315,6 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
     for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
     const double gain = L->gain;
     const double pre = L->pre;
-#ifdef VS_EXP_F32
-    vs_f32x2 ce[11], co[10], yp[12];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) ce[k] = (vs_f32x2){(float)L->a[2 * k + 1], (float)L->a[2 * k]};
-#pragma unroll
-    for (int k = 0; k < 10; ++k) co[k] = (vs_f32x2){(float)L->a[2 * k + 2], (float)L->a[2 * k + 1]};
-#pragma unroll
-    for (int k = 0; k < 12; ++k) yp[k] = (vs_f32x2){0.0f, 0.0f};
-    const float a1f = (float)L->a[0], a22f = (float)L->a[21], gainf = (float)L->gain, pref = (float)L->pre;
-#endif
     int16_t *__restrict__ orow = args.out + row * args.out_pitch;
     const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
     int n = 0, rslot = 0, spins = 0;
@@ -1291,9 +1325,60 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
     for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
     dg.t = vs_stamp();
 #endif
+    if (ready_min >= VS_WAVE) {
+      /* Every live lane must be ready (the threshold of deep rings, BASELINE config 3): all lanes
+       * of the group then share one position n, the loop is wave-uniform, and the super-step runs
+       * under the FULL exec mask -- lanes beyond n_lanes filter whatever their ring column holds
+       * and only their stores are masked.  What that buys: the window y[] is updated in place.
+       * Under a divergent "if (ready)" the compiler has to keep the old window alive for the
+       * lanes that sit out and copies all 24 doubles in and out of every super-step (2 of 55
+       * vector instructions per sample). */
+      live = false; /* the loop below does all the work of this wavefront */
+      double yu[VS_SS];
+#pragma unroll
+      for (int j = 0; j < VS_SS; ++j) yu[j] = 0.0; /* vowel_new.c:222-224 */
+      /* A wait that runs out (a protocol bug, or the fault injected by the tests) sets the error word
+       * and stops waiting: the remaining super-steps run on whatever the ring holds, the launch ends
+       * and vs_plan_status() reports it.  No second way out of the loop -- a "break" here would make
+       * the old and the new window meet at the loop latch, and the compiler would copy it again. */
+      bool gave_up = false;
+      for (int nu = 0; nu < N; nu += VS_SS) {
+        VS_DIAG_ADD(dg, 7)
+        for (int polls = 0; !gave_up; ++polls) {
+          #ifdef VS_EXP_F_ONLY
+          const int g_seen = N; /* timing experiment: the filter alone, never short of input */
+#else
+          const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+          const bool ready = !valid || (g_seen - nu >= VS_SS) || (g_seen >= N);
+          if (__all(ready)) break;
+          __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+          VS_DIAG_ADD(dg, 6)
+          if (polls > args.spin_limit) {
+            if (args.err && lane == 0) atomicOr(args.err, 2);
+            gave_up = true;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int outv[VS_SS];
+        vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
+        vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, yu, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                 nu, N, args.vec_ok != 0, outv, xpre, valid);
+        rslot += VS_SS;
+        if (rslot >= C) rslot = 0;
+        /* the ring reads above precede this store in the LDS queue: the slots are free */
+        VS_LDS_RELEASE();
+        __hip_atomic_store(&npub[lane], nu + VS_SS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        VS_DIAG_ADD(dg, 0)
+      }
+    }
     while (__any(live)) {
       VS_DIAG_ADD(dg, 7)
-      const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      #ifdef VS_EXP_F_ONLY
+          const int g_seen = N; /* timing experiment: the filter alone, never short of input */
+#else
+          const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const bool ready = live && ((g_seen - n >= VS_SS) || (g_seen >= N));
       const int n_live = __builtin_popcountll(__ballot(live));
@@ -1302,11 +1387,6 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-#ifdef VS_EXP_F32
-          if (ARITH == VS_ARITH_FMA)
-            vs_superstep_f32(ce, co, a1f, a22f, yp, gainf, pref, ring + rslot * VS_WAVE + lane, orow, n, N, args.vec_ok != 0);
-          else
-#endif
           vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
                                                    orow, n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
@@ -1315,7 +1395,7 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
           if (n >= N) live = false;
         }
         /* the ring reads above precede this store in the LDS queue: the slots are free */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        VS_LDS_RELEASE();
         __hip_atomic_store(&npub[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         spins = 0;
         VS_DIAG_ADD(dg, 0)
@@ -1546,6 +1626,16 @@ __device__ __forceinline__ int vs_round2int_literal(double x)
   else if (x < -32767) x = -32767;
   return (int)(int16_t)(int)floor(x);
 }
+/* both forms of the super-step's rounding against the literal one: vs_round2int() always, the
+ * half-down form wherever the super-step would not fall back (vs_superstep); returns the failures */
+__device__ __forceinline__ int vs_round2int_check(double x)
+{
+  const int want = vs_round2int_literal(x);
+  int bad = (vs_round2int(x) != want) ? 1 : 0;
+  const bool flagged = (__double2hiint(x) <= VS_R2I_Q1_HI) || ((uint32_t)__double2loint(x) == 0xFFFFFFFFu);
+  if (!flagged && vs_round2int_half_down(x) != want) bad += 1;
+  return bad;
+}
 
 /* flowgen_shimmer.c:387, 398, literally */
 __device__ __forceinline__ int vs_noise_w_literal(uint32_t r, int N)
@@ -1579,7 +1669,11 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     const int j = (int)(k % 64ull);
     const double frac = (j < 32) ? 0.5 + (double)(j - 16) * 0x1p-50 : (double)(j - 32) / 32.0;
     const double x = (double)base + frac;
-    if (vs_round2int(x) != vs_round2int_literal(x)) b3++;
+    b3 += vs_round2int_check(x);
+    /* the doubles around the integer itself, 16 each way (the largest double below a power of
+     * two is where x + 1 rounds up to the next integer) */
+    const double xi = __longlong_as_double(__double_as_longlong((double)base) + (long long)(j - 32));
+    b3 += vs_round2int_check(xi);
   }
   for (unsigned long long k = tid; k < 4096ull; k += nthreads) {
     /* -2^-e and -0.5 +- j ulps, e = 1..1074: where x - floor(x) rounds */
@@ -1587,9 +1681,23 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     const int j = (int)(k / 1075ull);
     const double tiny = -ldexp(1.0, -e) * (1.0 + 0.25 * (double)j);
     const double near = __longlong_as_double(__double_as_longlong(-0.5) + (long long)(e % 9) - 4 + 16 * j);
-    if (vs_round2int(tiny) != vs_round2int_literal(tiny)) b3++;
-    if (vs_round2int(near) != vs_round2int_literal(near)) b3++;
-    if (vs_round2int(-tiny) != vs_round2int_literal(-tiny)) b3++;
+    b3 += vs_round2int_check(tiny) + vs_round2int_check(near) + vs_round2int_check(-tiny);
+    /* the neighbours of +-2^-e: -2^-54 is the last member of the quirk set */
+    const double pw = ldexp(1.0, -e);
+    for (int d = -2; d <= 2; ++d) {
+      const double u = __longlong_as_double(__double_as_longlong(pw) + (long long)d);
+      b3 += vs_round2int_check(u) + vs_round2int_check(-u);
+    }
+  }
+  if (tid == 0) {
+    /* the quirk set is where the two forms differ, and the super-step's test catches all of it */
+    const double q[6] = {-0x1p-54, -0x1p-60, -5e-324, 0x1.fffffffffffffp-1, 0x1.fffffffffffffp+0, 0x1.fffffffffffffp+13};
+    for (int i = 0; i < 6; ++i) {
+      const bool flagged = (__double2hiint(q[i]) <= VS_R2I_Q1_HI) || ((uint32_t)__double2loint(q[i]) == 0xFFFFFFFFu);
+      if (!flagged || vs_round2int(q[i]) != vs_round2int_literal(q[i]) ||
+          vs_round2int_half_down(q[i]) + 1 != vs_round2int_literal(q[i]))
+        b3++;
+    }
   }
   {
     const int widths[16] = {1, 2, 3, 7, 100, 2801, 2802, 4095, 4096, 12345, 32767, 32768, 45001, 65534, 45533, 45534};
