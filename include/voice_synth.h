@@ -191,11 +191,11 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
  * measurements (tools/) and tests.  Values are validated here, once, and copied into every plan
  * made afterwards; nothing else can change what a plan launches -- in particular no environment
  * variable does, unless VS_DEBUG_TUNING=1 asks vs_ctx_create() to read the experiment knobs
- * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_GEN_LOW, VS_GEN_MIN, VS_WS_PRIO) through this
+ * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_WS_ROLES, VS_GEN_LOW, VS_GEN_MIN, VS_WS_PRIO) through this
  * same function.  NULL resets. */
 #define VS_KERNEL_AUTO 0
 #define VS_KERNEL_SINGLE 1 /* one wavefront per 64 utterances generates and filters */
-#define VS_KERNEL_WS 2     /* wave-specialised: a generator and a filter wavefront per 64 utterances */
+#define VS_KERNEL_WS 2     /* wave-specialised: two or three wavefronts per 64 utterances, one job each */
 #define VS_FAULT_WITHHOLD_PROGRESS 1 /* tests: the generator wavefront never publishes its progress */
 typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
@@ -207,6 +207,8 @@ typedef struct vs_tuning {
   int32_t spin_limit; /* polls before a waiting wavefront gives up with VS_ERR_INTERNAL */
   int32_t fault;      /* VS_FAULT_* */
   int32_t ws_filter_prio; /* s_setprio of the filter wavefront: 0 = default (3), 1..3, -1 = leave it at 0 */
+  int32_t ws_roles;   /* wavefronts per 64 utterances of the wave-specialised launch: 0 = the library's choice,
+                         2 = generator | filter, 3 = open phase | noise | filter (full grids) */
 } vs_tuning;
 int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
 /* Device self-test of the arithmetic shortcuts the kernels take: [0] division shortcut

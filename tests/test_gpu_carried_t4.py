@@ -58,13 +58,14 @@ def _carrying_cycles(lane, n):
     return count
 
 
-@pytest.mark.parametrize("kernel", [vs.VS_KERNEL_SINGLE, vs.VS_KERNEL_WS])
+@pytest.mark.parametrize("kernel", [dict(kernel=vs.VS_KERNEL_SINGLE), dict(kernel=vs.VS_KERNEL_WS, ws_roles=2),
+                                    dict(kernel=vs.VS_KERNEL_WS, ws_roles=3)])
 def test_power_sum_starts_at_the_carried_t4(kernel):
     lanes = [vs.lane_from_cli(fa, va, seed)[0] for fa, va, seed in FOUND] + _regime_lanes(509)
     n = 5000
     assert sum(_carrying_cycles(l, n) for l in lanes[:40]) > 100   # the batch is in the regime
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=kernel)
+    eng.set_tuning(**kernel)
     try:
         flow = eng.source(lanes, n)
         pcm = eng.synth(lanes, n)

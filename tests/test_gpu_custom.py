@@ -16,7 +16,8 @@ from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = {"single": vs.VS_KERNEL_SINGLE, "ws": vs.VS_KERNEL_WS}
+KERNELS = {"single": dict(kernel=vs.VS_KERNEL_SINGLE), "ws": dict(kernel=vs.VS_KERNEL_WS, ws_roles=2),
+           "ws3": dict(kernel=vs.VS_KERNEL_WS, ws_roles=3)}
 
 
 def _custom_lanes(n):
@@ -28,13 +29,13 @@ def _custom_lanes(n):
     return lanes, vs.num_samples(fs, dur)
 
 
-@pytest.mark.parametrize("kernel", ["single", "ws"])
+@pytest.mark.parametrize("kernel", ["single", "ws", "ws3"])
 def test_custom_coefficient_sets_per_lane(kernel):
     lanes, ns = _custom_lanes(100)
     assert len({tuple(lanes[l].A[:]) for l in range(100)}) > 60       # really per lane
     want = po.synth(lanes, ns)
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=KERNELS[kernel])
+    eng.set_tuning(**KERNELS[kernel])
     try:
         got = eng.synth(lanes, ns)
         assert np.array_equal(got, want), "lanes %s differ" % np.flatnonzero((got != want).any(axis=1))[:10]
@@ -82,12 +83,13 @@ def test_config5_blended_pole_sets_full_batch_sampled(engine):
     assert np.array_equal(pcm[pick], po.synth([lanes[i] for i in pick], ns))
 
 
+@pytest.mark.parametrize("roles", [2, 3])
 @pytest.mark.parametrize("pairs", [1, 2, 4])
-def test_every_workgroup_shape_of_the_ws_kernel_on_ragged_batches(pairs):
-    """1, 2 and 4 generator/filter pairs per workgroup (role-major layout), on batches that leave
-    pairs of the last workgroup partly or wholly without utterances"""
+def test_every_workgroup_shape_of_the_ws_kernel_on_ragged_batches(pairs, roles):
+    """1, 2 and 4 groups per workgroup, two and three wavefronts per group (role-major layout), on
+    batches that leave groups of the last workgroup partly or wholly without utterances"""
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=vs.VS_KERNEL_WS, ws_pairs=pairs)
+    eng.set_tuning(kernel=vs.VS_KERNEL_WS, ws_pairs=pairs, ws_roles=roles)
     try:
         for index, n in ((3, 130), (5, 321), (2, 64), (3, 1)):
             specs, fs, dur, _ = configs.config_specs(index, n)
@@ -110,15 +112,16 @@ def test_config2_at_its_real_batch(engine):
     assert np.array_equal(flow, po.source(lanes, ns))
 
 
-def test_ws_kernel_bounded_wait_reaches_the_caller():
-    """vs_tuning.fault withholds the generator wave's progress words: the filter wave's bounded
-    wait must run out, set the launch's error word and vs_synth must return VS_ERR_INTERNAL
-    instead of hanging or returning garbage"""
+@pytest.mark.parametrize("roles", [2, 3])
+def test_ws_kernel_bounded_wait_reaches_the_caller(roles):
+    """vs_tuning.fault withholds the generator wave's progress words: the bounded waits of the other
+    wavefronts (filter; noise and filter in the three-role kernel) must run out, set the launch's
+    error word and vs_synth must return VS_ERR_INTERNAL instead of hanging or returning garbage"""
     specs, fs, dur, _ = configs.config_specs(3, 200)
     lanes, d = vs.lanes_from_specs(specs)
     eng = vs.Engine(0)
     try:
-        eng.set_tuning(kernel=vs.VS_KERNEL_WS, fault=vs.VS_FAULT_WITHHOLD_PROGRESS, spin_limit=2000)
+        eng.set_tuning(kernel=vs.VS_KERNEL_WS, ws_roles=roles, fault=vs.VS_FAULT_WITHHOLD_PROGRESS, spin_limit=2000)
         with pytest.raises(vs.VsError) as e:
             eng.synth(lanes, 4000)
         assert e.value.code == _ffi.VS_ERR_INTERNAL
@@ -140,7 +143,7 @@ def test_ws_kernel_bounded_wait_reaches_the_caller():
 
 def test_tuning_is_validated(engine):
     lib = vs.load()
-    for bad in (dict(kernel=7), dict(ready_min=65), dict(ws_pairs=3), dict(gen_low=5), dict(gen_min=-1),
+    for bad in (dict(kernel=7), dict(ready_min=65), dict(ws_pairs=3), dict(gen_low=5), dict(gen_min=-1), dict(ws_roles=4),
                 dict(fault=9), dict(ring_slots=-24)):
         t = vs.Tuning()
         for k, v in bad.items():

@@ -105,17 +105,18 @@ def test_cycle_log_matches_oracle(engine):
             assert np.array_equal(recs[l][:n][name], r[name]), name
 
 
-KERNELS = {"single": vs.VS_KERNEL_SINGLE, "ws": vs.VS_KERNEL_WS}
+KERNELS = {"single": dict(kernel=vs.VS_KERNEL_SINGLE), "ws": dict(kernel=vs.VS_KERNEL_WS, ws_roles=2),
+           "ws3": dict(kernel=vs.VS_KERNEL_WS, ws_roles=3)}
 
 
-@pytest.mark.parametrize("kernel", ["single", "ws"])
+@pytest.mark.parametrize("kernel", ["single", "ws", "ws3"])
 def test_both_fused_kernels_bit_exact(kernel):
     """The plan picks the one-wave kernel for full grids and the wave-specialised kernel
     (generator wave + filter wave per 64 utterances, LDS progress words) for grids that leave
     half of the SIMDs empty; vs_ctx_set_tuning() forces either.  Both must be bit-exact on
     every shape."""
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=KERNELS[kernel])
+    eng.set_tuning(**KERNELS[kernel])
     try:
         for index, n in ((2, 96), (3, 200), (5, 130), (4, 70), (1, 1)):
             lanes, ns = _lanes(index, n)
@@ -131,7 +132,7 @@ def test_both_fused_kernels_bit_exact(kernel):
         eng.close()
 
 
-@pytest.mark.parametrize("kernel", ["single", "ws"])
+@pytest.mark.parametrize("kernel", ["single", "ws", "ws3"])
 def test_noise_below_t4_is_never_consumed_early(kernel):
     """-l gives a DC flow > 0, so the noise also covers [0, T4) of every cycle and is added to
     samples that were written earlier in the same cycle.  The wave-specialised kernel publishes
@@ -144,7 +145,7 @@ def test_noise_below_t4_is_never_consumed_early(kernel):
         lanes.append(lane)
     ns = vs.num_samples(16000, dur)
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=KERNELS[kernel])
+    eng.set_tuning(**KERNELS[kernel])
     try:
         for _ in range(3):
             got = eng.synth(lanes, ns)

@@ -255,15 +255,16 @@ def test_random_parameter_fuzz(engine):
     assert np.array_equal(flow, po.source(lanes, n))
 
 
-@pytest.mark.parametrize("kernel", [vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE])
+@pytest.mark.parametrize("kernel", [dict(kernel=vs.VS_KERNEL_AUTO), dict(kernel=vs.VS_KERNEL_SINGLE),
+                                    dict(kernel=vs.VS_KERNEL_WS, ws_roles=3)])
 def test_random_parameter_fuzz_large(kernel):
     """the same draw of command lines at scale: 12000 lanes (lanes that take the generator's short
     sequences next to lanes that cannot, every option on and off), every sample against the oracle,
-    with the default kernel choice and with the one-wave kernel forced"""
+    with the default kernel choice, with the one-wave kernel and with the three-role kernel forced"""
     lanes = _fuzz_lanes(20261004, 12000)
     n = 5000
     eng = vs.Engine(0)
-    eng.set_tuning(kernel=kernel)
+    eng.set_tuning(**kernel)
     try:
         got = eng.synth(lanes, n)
     finally:
@@ -286,15 +287,15 @@ def test_corner_parameter_fuzz():
     lanes = _corner_lanes(31337, 8000)
     n = 5000
     want = po.synth(lanes, n, threads=32)
-    for kernel in (vs.VS_KERNEL_AUTO, vs.VS_KERNEL_SINGLE):
+    for kernel in (dict(kernel=vs.VS_KERNEL_AUTO), dict(kernel=vs.VS_KERNEL_SINGLE), dict(kernel=vs.VS_KERNEL_WS, ws_roles=3)):
         eng = vs.Engine(0)
-        eng.set_tuning(kernel=kernel)
+        eng.set_tuning(**kernel)
         try:
             got = eng.synth(lanes, n)
         finally:
             eng.close()
         bad = int((got != want).any(axis=1).sum())
-        assert bad == 0, "%d lanes differ (kernel %d)" % (bad, kernel)
+        assert bad == 0, "%d lanes differ (kernel %s)" % (bad, kernel)
 
 
 def _is_fast(lane):

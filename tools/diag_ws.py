@@ -20,8 +20,14 @@ def main():
     for _ in range(2):
         plan.launch(vs.VS_KIND_SYNTH, out); eng.synchronize()
     a = eng.dev_download(dg, (grid, 16), np.uint64).astype(np.float64)
+    print("generator rounds per group %.1f (a lane has %.1f cycles on average), lanes per round %.1f" %
+          (a[:, 9].mean(), 0.0 if a[:, 9].mean() == 0 else a[:, 10].sum() / 64.0 / a.shape[0], a[:, 10].sum() / max(a[:, 9].sum(), 1.0)))
+    if a[:, 11].sum() > 0:
+        print("noise wavefront (three-role kernel): working %.1f, asleep %.1f ticks/sample" % (a[:, 11].mean() / ns, a[:, 12].mean() / ns))
     for w, names in ((0, GN), (1, FN)):
-        part = a[:, 8 * w:8 * w + 8]; tot = part.sum(axis=1).mean()
+        part = a[:, 8 * w:8 * w + 8].copy()
+        if w == 1: part[:, 1:6] = 0
+        tot = part.sum(axis=1).mean()
         print("wave %d (%s): ticks per sample %.0f" % (w, "generator" if w == 0 else "filter", tot / ns))
         for k in range(8):
             if names[k] != "-":

@@ -138,6 +138,7 @@ class Tuning(C.Structure):
         ("spin_limit", C.c_int32),
         ("fault", C.c_int32),
         ("ws_filter_prio", C.c_int32),
+        ("ws_roles", C.c_int32),
     ]
 
 

@@ -73,6 +73,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
       if ((v = getenv("VS_RING_SLOTS")) != nullptr) t.ring_slots = atoi(v);
       if ((v = getenv("VS_READY_MIN")) != nullptr) t.ready_min = atoi(v);
       if ((v = getenv("VS_WS_PAIRS")) != nullptr) t.ws_pairs = atoi(v);
+      if ((v = getenv("VS_WS_ROLES")) != nullptr) t.ws_roles = atoi(v);
       if ((v = getenv("VS_GEN_LOW")) != nullptr) t.gen_low = atoi(v);
       if ((v = getenv("VS_GEN_MIN")) != nullptr) t.gen_min = atoi(v);
       if ((v = getenv("VS_WS_PRIO")) != nullptr) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
@@ -104,6 +105,7 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->spin_limit < 0) return VS_ERR_ARG;
   if (t->fault != 0 && t->fault != VS_FAULT_WITHHOLD_PROGRESS) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
+  if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
   ctx->tuning = *t;
   return VS_OK;
 }
@@ -506,7 +508,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   int slots = 0, ready_min = 32;
   int ltab_entries = 0;
   size_t lds_bytes = 0;
-  int ws_pairs = 1, ws_pair_bytes = 0;
+  int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2;
   if (!filter_only) {
     int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
     if (rc != VS_OK) return rc;
@@ -557,6 +559,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       ws_pairs = (grid <= cus) ? 1 : (grid <= 2u * cus ? 2 : 4);
       if (tune.ws_pairs > 0) ws_pairs = tune.ws_pairs;
       while (ws_pairs > 1 && (size_t)ws_pairs * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs >>= 1;
+      /* Full grids (four groups per workgroup, the wavefronts of a group share a SIMD): three roles
+       * -- open phase | noise | filter -- if the extra progress words and order boxes still fit next
+       * to four rings.  Otherwise two: generator | filter. */
+      const int bytes3 = (int)((lds_bytes + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
+      size_t noisy = 0;
+      for (size_t l = 0; l < n_lanes; l++) noisy += (dl[l].flags & VS_DF_NOISE) ? 1 : 0;
+      /* only where there is noise to hand over: without it the third wavefront just relays
+       * progress words (BASELINE config 2's shape: 3.01 ms against 2.75 with two roles) */
+      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+      if (tune.ws_roles == 2) ws_roles = 2;
+      if (tune.ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+      if (ws_roles == 3) ws_pair_bytes = bytes3;
     }
   }
 
@@ -578,6 +592,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
+  p->ws_roles = ws_roles;
   p->ws_pair_bytes = ws_pair_bytes;
   p->filter_only = filter_only;
   p->pre1 = pre1 ? 1 : 0;
@@ -694,7 +709,7 @@ extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t
   const int ws = p->wave_specialised && kind == VS_KIND_SYNTH && !p->d_opow;
   const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
   if (ws)
-    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s>", p->ctx->arith, pre1 ? "true" : "false");
+    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, pre1 ? "true" : "false", p->ws_roles);
   else
     snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
              pre1 ? "true" : "false");
@@ -743,9 +758,15 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;
+  a.ws_roles = p->ws_roles;
   a.ws_pair_bytes = p->ws_pair_bytes;
-  a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : (p->ws_pairs == 4 ? 32 : 16);
-  a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : 2 * VS_SS;
+  /* a generator round starts when gen_min/64 of the lanes that still need cycles have room -- or at
+   * once when a lane is about to run its filter dry (fewer than gen_low samples buffered).  The
+   * open-phase wavefront of the three-role kernel is idle two thirds of the time and would start
+   * rounds for half of the lanes all day long (209 rounds at 58 % attendance instead of 141 at 86 %,
+   * profiles/r03_kernel_experiments.txt): it waits for everybody unless a lane is nearly dry. */
+  a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : (p->ws_roles == 3 ? 64 : (p->ws_pairs == 4 ? 32 : 16));
+  a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : (p->ws_roles == 3 ? 32 : 2 * VS_SS);
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;
   a.ws_filter_prio = p->tuning.ws_filter_prio == 0 ? 3 : (p->tuning.ws_filter_prio < 0 ? 0 : p->tuning.ws_filter_prio);

@@ -22,6 +22,11 @@
  *     phases behind it. */
 #define VS_DF_FAST 0x8u
 
+/* three-role kernel: order boxes per lane between the open-phase and the noise wavefront, and the
+ * LDS words per lane of a group's progress bookkeeping (gpub, npub, oseq, otak, 3 words per box) */
+#define VS_ORDER_DEPTH 2
+#define VS_SYNC_WORDS_3 (4 + 3 * VS_ORDER_DEPTH)
+
 #define VS_TRASH_ROWS 8 /* ring rows [C, C+8): where lanes that must not emit send their 8-sample trips */
 
 /* One utterance as the kernel reads it (296 bytes, 8-byte aligned).  Everything that is a
@@ -64,7 +69,8 @@ typedef struct VsKernelArgs {
   int vec_ok;         /* 1: every row start is 4-byte aligned, 16-byte vector stores allowed */
   int ltab_entries;   /* doubles reserved behind the ring for this wavefront's cos rows */
   int ready_min;      /* > 0: super-step threshold for every group (vs_tuning); 0: each group's own VsDevLane.ready_min */
-  int ws_pairs;       /* wave-specialised kernel: generator/filter pairs per workgroup (1 or 2) */
+  int ws_pairs;       /* wave-specialised kernels: groups of 64 utterances per workgroup (1, 2 or 4) */
+  int ws_roles;       /* wavefronts per group: 2 (generator | filter) or 3 (open phase | noise | filter) */
   int ws_pair_bytes;  /* LDS bytes of one pair: ring + trash row + cos rows + progress words, 16-byte multiple */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
   float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */

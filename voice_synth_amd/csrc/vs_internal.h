@@ -59,7 +59,8 @@ struct vs_plan {
   float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
   long opow_pitch;
   int wave_specialised;
-  int ws_pairs;      /* generator/filter pairs per workgroup of the wave-specialised launch */
+  int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
+  int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */
   int ws_pair_bytes; /* LDS bytes of one pair */
   int filter_only;   /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
   int pre1;          /* every lane has pre_emphasis == 1.0 (the reference's default) */

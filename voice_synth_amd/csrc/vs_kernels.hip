@@ -55,6 +55,7 @@ typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));   /* 
 struct VsDiag {
   unsigned long long acc[8];
   unsigned long long t;
+  unsigned long long rounds, attend; /* generator rounds and the lanes that took part in them */
 };
 #ifdef VS_DIAG
 __device__ __forceinline__ unsigned long long vs_stamp()
@@ -159,6 +160,7 @@ struct VsGen {
    * are made (vs_cycle_scalars) and before its samples are written (vs_cycle_emit) */
   float amp_next, S_next, K_next;
   bool pend;
+  int posted; /* three-role kernel: orders this lane has handed to the noise wavefront */
 };
 
 /* the Philox block the scalar draws of one cycle come from (local to vs_cycle_scalars) */
@@ -459,6 +461,115 @@ __device__ __forceinline__ int vs_noise_sample(const VsNoiseK &k, uint32_t r)
 }
 
 /*
+ * The noise of one closed phase on the short sequence (T4 == 0, a width the one-fma form is proved
+ * for): draw ordinal q = 0..m-1 of the cycle belongs to cycle sample T3 + q, the draws start at
+ * index d0 of the lane's stream.  Two Philox blocks (8 draws) per trip; word 0 of the first block
+ * has ordinal q0 in -3..0 (the scalar draws of this cycle sit in front of it), so the first trip
+ * masks its leading words.  A lane that is done (q0 >= m) sends its trips to the trash rows.
+ * The trips follow the Philox blocks, not the ring: a trip's 8 slots start anywhere and may wrap
+ * (compare + select per sample); the run itself moves on by 8 slots per trip.  T3 + q0 >= 1:
+ * VS_DF_FAST lanes have T2 >= 4.
+ * TAIL: the trip in which a lane ends stops AT the end.  Without it that trip runs up to 7 slots
+ * into the next cycle, which is fine when the same wavefront writes the next cycle afterwards, and
+ * not when another wavefront is already writing it (three-role kernel).
+ * wpos: ring slot of cycle sample 0; gbase: the utterance's sample count at cycle sample 0.
+ */
+template <bool PUB, bool TAIL>
+__device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, const VsRoundKeys &rk,
+                                               const VsNoiseK nk, uint32_t d0, int m, int wpos, int T3,
+                                               int gbase, int *gpub_lane)
+{
+  const uint32_t bfirst = d0 >> 2;
+  int q0 = (int)(4u * bfirst - d0);
+  uint32_t b = bfirst;
+  VsRun8 run = vs_run8(ring, wpos, C, T3 + q0, lane);
+  char *const trashA = vs_run8_trash(ring, C, lane).A;
+  {
+    uint32_t o[8];
+    vs_philox2(b, rk, o);
+    int xv[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
+    /* words in front of the cycle's first noise draw (q0 + w < 0) go to the trash rows */
+    char *A = (m > 0) ? run.A : trashA, *B = (m > 0) ? run.B : trashA;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      char *pw = (w < run.kw) ? A : B;
+      if (w < 3) pw = (q0 + w >= 0) ? pw : trashA;
+      if (TAIL) pw = (q0 + w < m) ? pw : trashA;
+      *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
+    }
+    q0 += 8;
+    b += 2u;
+    vs_run8_advance(run, C);
+    if (PUB) {
+      const int done = (q0 < m) ? q0 : m;
+      VS_LDS_RELEASE();
+      __hip_atomic_store(gpub_lane, gbase + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  int trip = 0;
+  while (__any(q0 < m)) {
+    uint32_t o[8];
+    vs_philox2(b, rk, o);
+    int xv[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
+    /* a lane that is done sends the trip to the trash rows */
+    char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
+    if (TAIL && __any((q0 < m) && (q0 + 8 > m))) {
+      /* some lane ends inside this trip: its slots behind the end go to the trash rows too */
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        char *pw = (w < run.kw) ? A : B;
+        pw = (q0 + w < m) ? pw : trashA;
+        *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
+      }
+    } else {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) *(int16_t *)(((w < run.kw) ? A : B) + w * VS_RING_STEP) = (int16_t)xv[w];
+    }
+    q0 += 8;
+    b += 2u;
+    vs_run8_advance(run, C);
+    ++trip;
+    if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
+      const int done = (q0 < m) ? q0 : m;
+      VS_LDS_RELEASE();
+      __hip_atomic_store(gpub_lane, gbase + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+/*
+ * Three-role kernel: what the open-phase wavefront hands to the noise wavefront for one cycle of
+ * one lane -- three LDS words per lane and a sequence number.
+ *   word 0 = d0                 draw index of the cycle's first noise draw
+ *   word 1 = T3 | T << 16       the noise covers cycle samples [T3, T); T3 == T: nothing to add
+ *   word 2 = NoiseDistWidth     (<= VS_NDW_FAST)
+ *   oseq   = orders posted so far (written last; the LDS keeps it behind the three words)
+ * VS_ORDER_DEPTH orders per lane may be outstanding (order k lives in box k % depth): the open-phase
+ * wavefront posts the next one only when oseq - otak < depth, otak being the orders the noise
+ * wavefront has taken (copied).  With one box the two wavefronts fall into lockstep and lanes that
+ * just missed a batch of the noise wavefront sit out the next round (rounds at 58 % attendance
+ * instead of 86 %, profiles/r03_kernel_experiments.txt).
+ */
+struct VsOrderBox {
+  int *w, *oseq, *otak; /* w: [VS_ORDER_DEPTH][3][64] ints in LDS; oseq, otak: [64] */
+};
+__device__ __forceinline__ void vs_post_order(const VsOrderBox &ob, int lane, VsGen &s, uint32_t d0, int T3, int T, int NDW)
+{
+  int *box = ob.w + (s.posted & (VS_ORDER_DEPTH - 1)) * (3 * VS_WAVE) + lane;
+  box[0] = (int)d0;
+  box[VS_WAVE] = T3 | (T << 16);
+  box[2 * VS_WAVE] = NDW;
+  s.posted += 1;
+  VS_LDS_RELEASE();
+  __hip_atomic_store(&ob.oseq[lane], s.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+/*
  * Second half of a cycle, for every lane that is ACTIVE in the EXEC mask (the caller wraps the
  * call in "if (want)"): the samples -- statement-by-statement restatement of
  * flowgen_shimmer.c:317-423 (scalar form: oracle/vs_oracle.c).
@@ -475,11 +586,11 @@ __device__ __forceinline__ int vs_noise_sample(const VsNoiseK &k, uint32_t r)
  * ltab is this wavefront's copy of the cos rows in LDS (rows padded to a multiple of 8 with
  * 1.0), c.tab_off the lane's row in it.
  */
-template <bool LOG, bool PUB = false>
+template <bool LOG, bool PUB = false, bool SPLIT = false>
 __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t *ring, int C,
                                               int lane, int N, const double *ltab,
                                               vs_cycle_rec *logrow, int log_cap, VsDiag &dg,
-                                              int *gpub_lane = nullptr)
+                                              int *gpub_lane = nullptr, const VsOrderBox ord = VsOrderBox())
 {
   VS_DIAG_ADD(dg, 7)
   const float Amplitude = s.amp_next;
@@ -677,6 +788,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
   }
   float x_pow = 0.0f, w_pow = 0.0f;
   const bool noisy = (c.flags & VS_DF_NOISE) != 0;
+  bool handed = false; /* three-role kernel: the cycle's noise went to the noise wavefront as an order */
 
   if (!noisy) {
     /* ---- closed phase without noise: fg:334-336 ---- */
@@ -715,61 +827,15 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
        * sit in front of it), so the first trip masks its leading words.  A lane that is done
        * (q0 >= m) sends its trips to the trash rows; the trip in which a lane ends may run up to
        * 7 slots into the next cycle. */
-      VsRoundKeys rk;
-      vs_round_keys(c.key0, c.key1, rk);
-      const VsNoiseK nk = vs_noise_consts(NDW, c.dcs);
-      int q0 = (int)(4u * bfirst - d0);
-      uint32_t b = bfirst;
-      /* The trips follow the Philox blocks, not the ring: a trip's 8 slots start anywhere and may
-       * wrap (compare + select per sample); the run itself moves on by 8 slots per trip instead of
-       * being worked out from the cycle's start every time.  T3 + q0 >= 1: VS_DF_FAST lanes have
-       * T2 >= 4. */
-      VsRun8 run = vs_run8(ring, s.wpos, C, T3 + q0, lane);
-      char *const trashA = vs_run8_trash(ring, C, lane).A;
-      {
-        uint32_t o[8];
-        vs_philox2(b, rk, o);
-        int xv[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-        /* words in front of the cycle's first noise draw (q0 + w < 0) go to the trash rows */
-        char *A = (m > 0) ? run.A : trashA, *B = (m > 0) ? run.B : trashA;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          char *pw = (w < run.kw) ? A : B;
-          if (w < 3) pw = (q0 + w >= 0) ? pw : trashA;
-          *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
-        }
-        q0 += 8;
-        b += 2u;
-        vs_run8_advance(run, C);
-        if (PUB) {
-          const int done = (q0 < m) ? q0 : m;
-          VS_LDS_RELEASE();
-          __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      int trip = 0;
-      while (__any(q0 < m)) {
-        uint32_t o[8];
-        vs_philox2(b, rk, o);
-        int xv[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-        /* a lane that is done sends the trip to the trash rows */
-        char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) *(int16_t *)(((w < run.kw) ? A : B) + w * VS_RING_STEP) = (int16_t)xv[w];
-        q0 += 8;
-        b += 2u;
-        vs_run8_advance(run, C);
-        ++trip;
-        if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
-          const int done = (q0 < m) ? q0 : m;
-          VS_LDS_RELEASE();
-          __hip_atomic_store(gpub_lane, s.g + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+      if (SPLIT) {
+        /* three-role kernel: the noise wavefront does this part -- post the order (the open phase
+         * is in the ring: the LDS keeps the order behind those stores) */
+        vs_post_order(ord, lane, s, d0, T3, T, NDW);
+        handed = true;
+      } else {
+        VsRoundKeys rk;
+        vs_round_keys(c.key0, c.key1, rk);
+        vs_noise_trips<PUB, false>(ring, C, lane, rk, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
       }
     } else if (T4 == 0) {
       /* T4 == 0 on the general sequence: the draws map to i = T3 + q, q = 0..m-1 */
@@ -865,6 +931,10 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
     }
   }
 
+  /* three-role kernel: a cycle this wavefront has written in full still goes through the noise
+   * wavefront, which is the one that publishes progress to the filter -- as an empty order */
+  if (SPLIT && !handed) vs_post_order(ord, lane, s, s.d, T, T, 0);
+
   /* ---- emit bookkeeping: fg:413-423 ---- */
   s.cyc += 1;
   s.g += T;
@@ -919,19 +989,44 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
     }
   } else {
+    /* the first 8 now, the rest in two more batches issued from inside the sample loop (each a
+     * chunk ahead of its use): 24 ring samples held at once are 16 registers too many */
 #pragma unroll
-    for (int t = 0; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+    for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_WAVE];
   }
+
+  /* results leave in chunks of 8 samples = one 16-byte store, as soon as a chunk is complete: 24
+   * pending results would cost 24 registers (the three-role kernel runs at 168 per wavefront) */
+  auto put8 = [&](int k) {
+    if (whole) {
+      vs_u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+      if (store_ok) *(vs_u32x4 *)(orow + n + 8 * k) = v;
+    } else {
+#pragma unroll
+      for (int t = 8 * k; t < 8 * k + 8; ++t)
+        if (store_ok && (n + t < N)) orow[n + t] = (int16_t)outv[t];
+    }
+  };
 
   if (KIND == VS_KIND_SOURCE) {
 #pragma unroll
+    for (int t = 8; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+#pragma unroll
     for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t]; /* the flow itself */
+#pragma unroll
+    for (int k = 0; k < VS_SS / 8; ++k) put8(k);
   } else {
     const double ym1 = y[VS_SS - 1]; /* y[n-1]: only the quirk path below needs it once y[23] is replaced */
     int qhi = 0x7FFFFFFF;            /* signed minimum of the high words of the rounded values */
     uint32_t qlo = 0u;               /* unsigned maximum of their low words */
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t) {
+      if (KIND != VS_KIND_FILTER && (t & 7) == 0 && t + 8 < VS_SS) {
+#pragma unroll
+        for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_WAVE];
+      }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
       double acc = (double)xin[t] * gain;
       const double y1 = y[(t + VS_SS - 1) % VS_SS];
@@ -959,6 +1054,9 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       const double o = PRE1 ? (acc - y1)
                             : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
       outv[t] = vs_round2int_half_down(o);
+      /* rounded HERE: left to itself the compiler keeps all 24 arguments (48 registers) and rounds
+       * them behind the quirk test below, where the other branch does not need the results */
+      asm volatile("" : "+v"(outv[t]));
       {
         const int ohi = __double2hiint(o);
         const uint32_t olo = (uint32_t)__double2loint(o);
@@ -966,13 +1064,15 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         qlo = (olo > qlo) ? olo : qlo;
       }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+      if ((t & 7) == 7) put8(t >> 3);
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
       __builtin_amdgcn_sched_barrier(0);
     }
     if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu))) {
       /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
-       * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again, literally */
+       * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again,
+       * literally, and store it again */
 #pragma unroll
       for (int t = 0; t < VS_SS; ++t) {
         const double y1 = (t == 0) ? ym1 : y[t - 1];
@@ -980,24 +1080,9 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
                               : ((ARITH == VS_ARITH_EXACT) ? (y[t] - pre * y1) : __builtin_fma(-pre, y1, y[t]));
         outv[t] = vs_round2int(o);
       }
+#pragma unroll
+      for (int k = 0; k < VS_SS / 8; ++k) put8(k);
     }
-  }
-
-  if (whole) {
-    vs_u32x4 v[VS_SS / 8];
-#pragma unroll
-    for (int k = 0; k < VS_SS / 8; ++k) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[k][e] = vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
-    }
-    if (store_ok) {
-#pragma unroll
-      for (int k = 0; k < VS_SS / 8; ++k) *(vs_u32x4 *)(orow + n + 8 * k) = v[k];
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < VS_SS; ++t)
-      if (store_ok && (n + t < N)) orow[n + t] = (int16_t)outv[t];
   }
 }
 
@@ -1014,7 +1099,7 @@ __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsC
   s.d = 0u;
   s.dp0 = 0.0f; s.ds0 = 0.0f;
   s.T4 = 0; s.T = c.P; s.g = 0; s.wpos = 0; s.cyc = 0;
-  s.amp_next = 0.0f; s.S_next = 0.0f; s.K_next = 0.0f; s.pend = false;
+  s.amp_next = 0.0f; s.S_next = 0.0f; s.K_next = 0.0f; s.pend = false; s.posted = 0;
 }
 
 /* Stage the cos rows this wavefront needs in LDS: one pass per distinct T2 among its lanes
@@ -1176,208 +1261,297 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 }
 
 /*
- * Wave-specialised fused kernel: the same 64 utterances are served by TWO wavefronts -- one only
- * generates (vs_cycle_scalars + vs_cycle_emit), the other only filters (vs_superstep) -- coupled
- * through the LDS ring and two per-lane progress words.  A workgroup holds one, two or four such
- * pairs.  This is what the fused kind launches by default (vs_plan_create):
- *   - grids that leave at least half of the chip's SIMDs empty (e.g. BASELINE config 4 sharded
- *     over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024 SIMDs): every wavefront has a
- *     SIMD of its own and a launch takes max(generator, filter) instead of their sum (1.35-1.6x);
- *   - full grids (BASELINE config 3): four pairs per 512-thread workgroup, wavefronts laid out
- *     role-major so that every SIMD hosts the generator and the filter of one pair, the filter
- *     wavefront at raised priority.  One wavefront alone issues an instruction every ~5.3 cycles
- *     and the pipe is free after 4; two fill each other's gaps (13 % faster than the one-wave
- *     kernel; pair-major workgroups without the priority were no faster).
+ * Wave-specialised fused kernels: the same 64 utterances are served by SEVERAL wavefronts, each with
+ * one job, coupled through the LDS ring and a few per-lane progress words.  This is what the fused
+ * kind launches by default (vs_plan_create):
  *
- * Hand-off (workgroup scope, LDS only):
- *   gpub[l] = samples lane l's generator has written to the ring   (written by wave 0)
- *   npub[l] = samples lane l's filter has read from the ring        (written by wave 1)
- * The LDS executes one wavefront's operations in order, so "ring writes, then gpub" on one
- * side and "gpub read, then ring reads" on the other is a release/acquire pair; the fences
- * below keep the compiler from reordering.  Wave 0 writes slots of [g, g+T) only when
- * g - npub + T <= C (T = the cycle's period, fixed by vs_cycle_scalars), i.e. never over
- * samples the filter has not consumed.
+ *   two roles (generator | filter) -- grids that leave at least half of the chip's SIMDs empty
+ *     (e.g. BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024
+ *     SIMDs): one or two pairs per workgroup, every wavefront has a SIMD of its own and a launch
+ *     takes max(generator, filter) instead of their sum (1.35-1.6x);
  *
- * Progress: a lane that is short of 24 samples always has room for its next cycle, and wave 0
- * generates whenever such a lane exists; if no lane has room every lane holds more than 24
- * samples and wave 1 runs.  Spins are bounded (args.spin_limit polls, then the error word of
- * the launch is set and the wave leaves) so that a protocol bug cannot hang the device.
+ *   three roles (open phase | noise | filter) -- full grids (BASELINE config 3: 1024 groups on 1024
+ *     SIMDs): four groups per 768-thread workgroup, one workgroup per CU, wavefronts laid out
+ *     role-major so that every SIMD hosts the three wavefronts of ONE group (a workgroup's wavefronts
+ *     are dealt to the CU's four SIMDs cyclically: w, w+4, w+8 share a SIMD).  Why three: a lone
+ *     wavefront issues one instruction -- vector, scalar or LDS alike -- every ~5.25 cycles, and the
+ *     filter wavefront at raised priority leaves a second wavefront about a quarter of that
+ *     (tools/ubench/ubench3.hip), so a launch of the two-role kernel takes about 0.74 x filter + generator:
+ *     whatever the generator cannot do in the filter's shadow it does ALONE on its SIMD while the
+ *     filter sleeps.  Two generator wavefronts side by side run at 5.25 and 11 cycles per
+ *     instruction (ubench4.hip), i.e. that part goes ~1.5x faster when the generator's work is cut
+ *     in two: jitter / shimmer / both flanks here, the closed phase's noise there.
+ *
+ * Hand-off (workgroup scope, LDS only), per lane l:
+ *   gpub[l] = samples of l that are complete in the ring     (written by the generator / by the noise wavefront)
+ *   npub[l] = samples of l the filter has read from the ring  (written by the filter wavefront)
+ *   three roles: oseq[l] / otak[l] = orders posted by the open-phase wavefront / taken by the noise
+ *   wavefront, ord[0..2][l] = the order (vs_post_order): which draws, which samples, what width.
+ * The LDS executes one wavefront's operations in order, so "ring writes, then gpub" on one side and
+ * "gpub read, then ring reads" on the other is a release/acquire pair; the fences keep the compiler
+ * from reordering.  A cycle's slots [g, g+T) are written only when g - npub + T <= C (T = the cycle's
+ * period, fixed by vs_cycle_scalars), i.e. never over samples the filter has not consumed.  In the
+ * three-role kernel two wavefronts write the ring at the same time -- cycle c's noise and cycle
+ * c+1's flanks -- so the noise wavefront stops exactly at the end of its cycle (vs_noise_trips<TAIL>),
+ * while the open-phase wavefront only ever runs past a phase INSIDE its own cycle and finishes all
+ * of that before it posts the order.
+ *
+ * Progress: a lane that is short of 24 samples always has room for its next cycle, and a generator
+ * round starts whenever such a lane exists; if no lane has room every lane holds more than 24 samples
+ * and the filter runs.  Spins are bounded (args.spin_limit polls, then the error word of the launch
+ * is set and the wavefront leaves) so that a protocol bug cannot hang the device.
  */
 #ifndef VS_POLL_SLEEP
 #define VS_POLL_SLEEP 32 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one (A/B: 1, 2, 8, 32 -- 32 best by ~2 %) */
 #endif
 
-template <int ARITH, bool PRE1>
-__global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs args)
+/* what every role of a group needs to find its lane, its ring and its progress words */
+struct VsGroup {
+  const VsDevLane *L;
+  int16_t *ring;
+  double *ltab;
+  int *gpub, *npub;
+  VsOrderBox ord;
+  long group, row;
+  int lane, N, C;
+  bool valid;
+};
+
+/* The generator role of the two-role kernel (SPLIT = false: whole cycles) and the open-phase role of
+ * the three-role kernel (SPLIT = true: jitter, shimmer and both flanks; the cycle's noise leaves as
+ * an order, and progress is published by the noise wavefront only). */
+template <bool SPLIT>
+__device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, const VsGroup &g)
 {
-  extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
-
-  /* A workgroup holds ws_pairs generator/filter pairs (blockDim = 128 * ws_pairs).  Its
-   * wavefronts are laid out ROLE-MAJOR -- all generators first, then all filters -- because a
-   * workgroup's wavefronts are dealt to the CU's four SIMDs cyclically:
-   *   2 pairs (256 threads, half-filled chip): four wavefronts on four SIMDs, one each;
-   *   4 pairs (512 threads, one workgroup per CU, full chip): wavefront w and w+4 share a SIMD,
-   *     i.e. every SIMD hosts the generator AND the filter of the same pair -- never two filters
-   *     (which would halve the longer stream's issue rate) and never two generators. */
-  const int npairs = (int)blockDim.x >> 7;
-  const int widx = (int)threadIdx.x >> 6;
-  const int wave = widx / npairs; /* 0: generator, 1: filter */
-  const int pair = widx - wave * npairs;
-  const int lane = (int)threadIdx.x & (VS_WAVE - 1);
-  const long group = (long)blockIdx.x * (long)(blockDim.x >> 7) + pair;
-  const long gl = group * VS_WAVE + lane;
-  const bool valid = gl < (long)args.n_lanes;
-  const VsDevLane *__restrict__ L = args.lanes + (valid ? gl : (long)args.n_lanes - 1);
-  const int N = args.n_samples;
-  const int C = args.ring_slots;
-  int16_t *ring = lds_base + (size_t)pair * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
-  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE);
-  int *gpub = (int *)(ltab + args.ltab_entries);
-  int *npub = gpub + VS_WAVE;
-  const long row = (long)L->row;
-
-  if (wave == 0) gpub[lane] = 0;
-  else npub[lane] = 0;
-  __syncthreads();
-
-#ifdef VS_EXP_G_ONLY
-  if (wave != 0) return;
-#endif
-#ifdef VS_EXP_F_ONLY
-  if (wave == 0) return;
-#endif
-  if (wave == 0) {
-    /* ------------------------------- generator wave ------------------------------- */
-    VsCfg c;
-    VsGen s;
-    VsDiag dg;
+  const int lane = g.lane, N = g.N, C = g.C;
+  VsCfg c;
+  VsGen s;
+  VsDiag dg;
 #ifdef VS_DIAG
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
-    dg.t = vs_stamp();
+  for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+  dg.rounds = dg.attend = 0;
+  dg.t = vs_stamp();
 #endif
-    vs_load_cfg(L, c, s);
-    vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
-    int spins = 0;
-    for (;;) {
-      /* tests (vs_tuning.fault): a generator that never publishes -- the filter wave's bounded
-       * wait must run out and reach the caller as VS_ERR_INTERNAL */
-      if (args.fault == VS_FAULT_WITHHOLD_PROGRESS) break;
-      const bool need = valid && (s.g < N);
-      if (!__any(need)) break;
-      if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
-#ifdef VS_EXP_G_ONLY
-      const int n_seen = s.g; /* timing experiment: the generator alone, never short of room */
+  vs_load_cfg(g.L, c, s);
+  vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
+  int spins = 0;
+  for (;;) {
+    /* tests (vs_tuning.fault): a generator that never publishes -- the bounded waits of the other
+     * wavefronts must run out and reach the caller as VS_ERR_INTERNAL */
+    if (args.fault == VS_FAULT_WITHHOLD_PROGRESS) break;
+    const bool need = g.valid && (s.g < N);
+    if (!__any(need)) break;
+    if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
+#ifdef VS_TIMING_GENERATOR_ONLY
+    const int n_seen = s.g; /* timing build: the generator alone, never short of room */
 #else
-      const int n_seen = __hip_atomic_load(&npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int n_seen = __hip_atomic_load(&g.npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-      const bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
-      const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
-      const int n_need = __builtin_popcountll(__ballot(need));
-      const int n_want = __builtin_popcountll(__ballot(want));
-      if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
-        if (want) vs_cycle_emit<false, true>(c, s, ring, C, lane, N, ltab, nullptr, 0, dg, &gpub[lane]);
-        VS_LDS_RELEASE();
-        __hip_atomic_store(&gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        spins = 0;
+    bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
+    if (SPLIT) {
+      /* ... and one of the lane's order boxes is free */
+      const int taken = __hip_atomic_load(&g.ord.otak[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      want = want && (s.posted - taken < VS_ORDER_DEPTH);
+    }
+    const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
+    const int n_need = __builtin_popcountll(__ballot(need));
+    const int n_want = __builtin_popcountll(__ballot(want));
+    if ((n_want > 0) && ((n_want * 64 >= n_need * args.gen_min) || __any(hungry))) {
+#ifdef VS_DIAG
+      dg.rounds += 1;
+      dg.attend += (unsigned long long)n_want;
+#endif
+      if (SPLIT) {
+        if (want) vs_cycle_emit<false, false, true>(c, s, g.ring, C, lane, N, g.ltab, nullptr, 0, dg, nullptr, g.ord);
       } else {
-        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
-        VS_DIAG_ADD(dg, 6)
-        if (++spins > args.spin_limit) {
-          if (args.err && lane == 0) atomicOr(args.err, 1);
-          break;
-        }
+        if (want) vs_cycle_emit<false, true, false>(c, s, g.ring, C, lane, N, g.ltab, nullptr, 0, dg, &g.gpub[lane]);
+        VS_LDS_RELEASE();
+        __hip_atomic_store(&g.gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      spins = 0;
+    } else {
+      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      VS_DIAG_ADD(dg, 6)
+      if (++spins > args.spin_limit) {
+        if (args.err && lane == 0) atomicOr(args.err, 1);
+        break;
       }
     }
+  }
 #ifdef VS_DIAG
-    if (args.diag && lane == 0) {
+  if (args.diag && lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) args.diag[(size_t)group * 16 + k] = dg.acc[k];
-    }
+    for (int k = 0; k < 8; ++k) args.diag[(size_t)g.group * 16 + k] = dg.acc[k];
+    args.diag[(size_t)g.group * 16 + 9] = dg.rounds; /* slots 9, 10: unused by the filter wavefront */
+    args.diag[(size_t)g.group * 16 + 10] = dg.attend;
+  }
 #endif
-    if (args.ncyc && valid) args.ncyc[row] = s.cyc;
-  } else {
-    /* --------------------------------- filter wave --------------------------------- */
-    /* When a generator and a filter wave share a SIMD (full grids), VALU issue goes to the
-     * higher priority first: the filter wave is the longer of the two instruction streams, so
-     * it issues as if it were alone and the generator fills the slots it leaves.  Without this
-     * the two alternate and the launch takes twice the filter's time. */
-    if (args.ws_filter_prio >= 3) __builtin_amdgcn_s_setprio(3);
-    else if (args.ws_filter_prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (args.ws_filter_prio == 1) __builtin_amdgcn_s_setprio(1);
-    double a[VS_ORDER + 1];
-    double y[VS_SS];
-    a[0] = 1.0;
+  if (args.ncyc && g.valid) args.ncyc[g.row] = s.cyc;
+}
+
+/* The noise role of the three-role kernel: takes the orders of the open-phase wavefront, adds the
+ * closed phase's noise (flowgen_shimmer.c:385-406, vs_noise_trips) and is the one that publishes a
+ * lane's progress to the filter: the open phase when it takes the order, the closed phase trip by
+ * trip.  The round keys of a lane's Philox stream are made once per launch here. */
+__device__ __forceinline__ void vs_noise_wave(const VsKernelArgs &args, const VsGroup &g)
+{
+  const int lane = g.lane, N = g.N, C = g.C;
+  VsRoundKeys rk;
+  vs_round_keys(g.L->key0, g.L->key1, rk);
+  const int dcs = g.L->dcs;
+  int taken = 0; /* orders of this lane dealt with */
+  int gend = 0;  /* samples of this lane that are complete = where its next cycle starts */
+  int wpos = 0;  /* ring slot of sample gend */
+  int spins = 0;
+#ifdef VS_DIAG
+  VsDiag dg;
 #pragma unroll
-    for (int j = 1; j <= VS_ORDER; ++j) a[j] = L->a[j - 1];
+  for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+  dg.rounds = dg.attend = 0;
+  dg.t = vs_stamp();
+#endif
+  for (;;) {
+    const bool open = g.valid && (gend < N);
+    if (!__any(open)) break;
+    const int posted = __hip_atomic_load(&g.ord.oseq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const bool have = open && (posted != taken);
+    if (__any(have)) {
+      if (have) {
+        const int *box = g.ord.w + (taken & (VS_ORDER_DEPTH - 1)) * (3 * VS_WAVE) + lane;
+        const uint32_t d0 = (uint32_t)box[0];
+        const int w1 = box[VS_WAVE];
+        const int NDW = box[2 * VS_WAVE];
+        taken += 1;
+        /* the three reads above precede this store in the LDS queue: the box is free again */
+        VS_LDS_RELEASE();
+        __hip_atomic_store(&g.ord.otak[lane], taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int T3 = w1 & 0xFFFF, T = (int)((unsigned)w1 >> 16);
+        const int m = T - T3;
+        /* the open phase [0, T3) of this cycle is in the ring (it was before the order was posted) */
+        __hip_atomic_store(&g.gpub[lane], gend + T3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__any(m > 0)) {
+          vs_noise_trips<true, true>(g.ring, C, lane, rk, vs_noise_consts(NDW, dcs), d0, m, wpos, T3, gend,
+                                     &g.gpub[lane]);
+        }
+        gend += T;
+        wpos += T; /* T <= ring_slots */
+        if (wpos >= C) wpos -= C;
+      }
+      spins = 0;
+      VS_DIAG_ADD(dg, 4)
+    } else {
+      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      VS_DIAG_ADD(dg, 6)
+      if (++spins > args.spin_limit) {
+        if (args.err && lane == 0) atomicOr(args.err, 4);
+        break;
+      }
+    }
+  }
+#ifdef VS_DIAG
+  if (args.diag && lane == 0) { /* slots 11, 12: unused by the filter wavefront */
+    args.diag[(size_t)g.group * 16 + 11] = dg.acc[4];
+    args.diag[(size_t)g.group * 16 + 12] = dg.acc[6];
+  }
+#endif
+}
+
+/* The filter role: super-steps of 24 samples for every lane that holds them (vs_superstep).
+ * PARTIAL: groups whose threshold is below 64 lanes run super-steps with the ready lanes only (the
+ * two-role kernel); without it every group waits for all of its live lanes (the three-role kernel:
+ * the second copy of the window that a partial super-step needs does not fit its 168 registers). */
+template <int ARITH, bool PRE1, bool PARTIAL>
+__device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const VsGroup &g)
+{
+  const int lane = g.lane, N = g.N, C = g.C;
+  const VsDevLane *__restrict__ L = g.L;
+  int16_t *ring = g.ring;
+  int *gpub = g.gpub, *npub = g.npub;
+  const bool valid = g.valid;
+  /* When wavefronts share a SIMD (full grids), VALU issue goes to the higher priority first: the
+   * filter is the longest of the instruction streams, so it issues as if it were alone and the
+   * others fill the slots it leaves.  Without this the hardware prefers the OLDEST wavefront -- the
+   * generator -- and the launch takes longer (profiles/r02_ws_full_grid_sweep.txt). */
+  if (args.ws_filter_prio >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (args.ws_filter_prio == 2) __builtin_amdgcn_s_setprio(2);
+  else if (args.ws_filter_prio == 1) __builtin_amdgcn_s_setprio(1);
+  double a[VS_ORDER + 1];
+  a[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j <= VS_ORDER; ++j) a[j] = L->a[j - 1];
+  const double gain = L->gain;
+  const double pre = L->pre;
+  int16_t *__restrict__ orow = args.out + g.row * args.out_pitch;
+  const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
+#ifdef VS_DIAG
+  VsDiag dg;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
+  dg.t = vs_stamp();
+#endif
+  if (!PARTIAL || ready_min >= VS_WAVE) {
+    /* Every live lane must be ready (the threshold of deep rings, BASELINE config 3): all lanes
+     * of the group then share one position n, the loop is wave-uniform, and the super-step runs
+     * under the FULL exec mask -- lanes beyond n_lanes filter whatever their ring column holds
+     * and only their stores are masked.  What that buys: the window y[] is updated in place.
+     * Under a divergent "if (ready)" the compiler has to keep the old window alive for the
+     * lanes that sit out and copies all 24 doubles in and out of every super-step (2 of 55
+     * vector instructions per sample). */
+    double y[VS_SS];
 #pragma unroll
     for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
-    const double gain = L->gain;
-    const double pre = L->pre;
-    int16_t *__restrict__ orow = args.out + row * args.out_pitch;
-    const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
+    /* A wait that runs out (a protocol bug, or the fault injected by the tests) sets the error word
+     * and stops waiting: the remaining super-steps run on whatever the ring holds, the launch ends
+     * and vs_plan_status() reports it.  No second way out of the loop -- a "break" here would make
+     * the old and the new window meet at the loop latch, and the compiler would copy it again. */
+    bool gave_up = false;
+    int rslot = 0;
+    for (int n = 0; n < N; n += VS_SS) {
+      VS_DIAG_ADD(dg, 7)
+      for (int polls = 0; !gave_up; ++polls) {
+#ifdef VS_TIMING_FILTER_ONLY
+        const int g_seen = N; /* timing build: the filter alone, never short of input */
+#else
+        const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+        const bool ready = !valid || (g_seen - n >= VS_SS) || (g_seen >= N);
+        if (__all(ready)) break;
+        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+        VS_DIAG_ADD(dg, 6)
+        if (polls > args.spin_limit) {
+          if (args.err && lane == 0) atomicOr(args.err, 2);
+          gave_up = true;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      int outv[VS_SS];
+      vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n, N,
+                                               args.vec_ok != 0, outv, xpre, valid);
+      rslot += VS_SS;
+      if (rslot >= C) rslot = 0;
+      /* the ring reads above precede this store in the LDS queue: the slots are free */
+      VS_LDS_RELEASE();
+      __hip_atomic_store(&npub[lane], n + VS_SS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      VS_DIAG_ADD(dg, 0)
+    }
+  } else {
+    /* shallower rings: a super-step as soon as ready_min/64 of the live lanes hold 24 samples; every
+     * lane has its own position n */
+    double y[VS_SS];
+#pragma unroll
+    for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
     int n = 0, rslot = 0, spins = 0;
     bool live = valid;
-#ifdef VS_DIAG
-    VsDiag dg;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dg.acc[k] = 0;
-    dg.t = vs_stamp();
-#endif
-    if (ready_min >= VS_WAVE) {
-      /* Every live lane must be ready (the threshold of deep rings, BASELINE config 3): all lanes
-       * of the group then share one position n, the loop is wave-uniform, and the super-step runs
-       * under the FULL exec mask -- lanes beyond n_lanes filter whatever their ring column holds
-       * and only their stores are masked.  What that buys: the window y[] is updated in place.
-       * Under a divergent "if (ready)" the compiler has to keep the old window alive for the
-       * lanes that sit out and copies all 24 doubles in and out of every super-step (2 of 55
-       * vector instructions per sample). */
-      live = false; /* the loop below does all the work of this wavefront */
-      double yu[VS_SS];
-#pragma unroll
-      for (int j = 0; j < VS_SS; ++j) yu[j] = 0.0; /* vowel_new.c:222-224 */
-      /* A wait that runs out (a protocol bug, or the fault injected by the tests) sets the error word
-       * and stops waiting: the remaining super-steps run on whatever the ring holds, the launch ends
-       * and vs_plan_status() reports it.  No second way out of the loop -- a "break" here would make
-       * the old and the new window meet at the loop latch, and the compiler would copy it again. */
-      bool gave_up = false;
-      for (int nu = 0; nu < N; nu += VS_SS) {
-        VS_DIAG_ADD(dg, 7)
-        for (int polls = 0; !gave_up; ++polls) {
-          #ifdef VS_EXP_F_ONLY
-          const int g_seen = N; /* timing experiment: the filter alone, never short of input */
-#else
-          const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-          const bool ready = !valid || (g_seen - nu >= VS_SS) || (g_seen >= N);
-          if (__all(ready)) break;
-          __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
-          VS_DIAG_ADD(dg, 6)
-          if (polls > args.spin_limit) {
-            if (args.err && lane == 0) atomicOr(args.err, 2);
-            gave_up = true;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int outv[VS_SS];
-        vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-        vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, yu, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
-                                                 nu, N, args.vec_ok != 0, outv, xpre, valid);
-        rslot += VS_SS;
-        if (rslot >= C) rslot = 0;
-        /* the ring reads above precede this store in the LDS queue: the slots are free */
-        VS_LDS_RELEASE();
-        __hip_atomic_store(&npub[lane], nu + VS_SS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        VS_DIAG_ADD(dg, 0)
-      }
-    }
     while (__any(live)) {
       VS_DIAG_ADD(dg, 7)
-      #ifdef VS_EXP_F_ONLY
-          const int g_seen = N; /* timing experiment: the filter alone, never short of input */
+#ifdef VS_TIMING_FILTER_ONLY
+      const int g_seen = N;
 #else
-          const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int g_seen = __hip_atomic_load(&gpub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const bool ready = live && ((g_seen - n >= VS_SS) || (g_seen >= N));
@@ -1387,8 +1561,8 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr,
-                                                   orow, n, N, args.vec_ok != 0, outv, xpre);
+          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                   N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
@@ -1408,13 +1582,73 @@ __global__ void __launch_bounds__(8 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs a
         }
       }
     }
-#ifdef VS_DIAG
-    if (args.diag && lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) args.diag[(size_t)group * 16 + 8 + k] = dg.acc[k];
-    }
-#endif
   }
+#ifdef VS_DIAG
+  if (args.diag && lane == 0) {
+    args.diag[(size_t)g.group * 16 + 8] = dg.acc[0];
+    args.diag[(size_t)g.group * 16 + 14] = dg.acc[6];
+    args.diag[(size_t)g.group * 16 + 15] = dg.acc[7];
+  }
+#endif
+}
+
+/* ROLES wavefronts per group of 64 utterances, args.ws_pairs groups per workgroup, wavefronts laid
+ * out role-major: role = wavefront / groups.  Two roles: 0 generator, 1 filter.  Three roles: 0 open
+ * phase, 1 noise, 2 filter (the hardware prefers the older of two wavefronts of equal priority:
+ * open phase before noise is the better order, tools/ubench/ubench4.hip). */
+template <int ARITH, bool PRE1, int ROLES>
+__global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
+
+  const int ngroups = (int)blockDim.x / (ROLES * VS_WAVE);
+  const int widx = (int)threadIdx.x >> 6;
+  const int role = widx / ngroups;
+  const int slot = widx - role * ngroups;
+  VsGroup g;
+  g.lane = (int)threadIdx.x & (VS_WAVE - 1);
+  g.group = (long)blockIdx.x * (long)ngroups + slot;
+  const long gl = g.group * VS_WAVE + g.lane;
+  g.valid = gl < (long)args.n_lanes;
+  g.L = args.lanes + (g.valid ? gl : (long)args.n_lanes - 1);
+  g.N = args.n_samples;
+  g.C = args.ring_slots;
+  g.ring = lds_base + (size_t)slot * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
+  g.ltab = (double *)(g.ring + (size_t)(g.C + VS_TRASH_ROWS) * VS_WAVE);
+  g.gpub = (int *)(g.ltab + args.ltab_entries);
+  g.npub = g.gpub + VS_WAVE;
+  g.ord.oseq = g.npub + VS_WAVE;
+  g.ord.otak = g.ord.oseq + VS_WAVE;
+  g.ord.w = g.ord.otak + VS_WAVE;
+  g.row = (long)g.L->row;
+
+  if (role == 0) {
+    g.gpub[g.lane] = 0;
+    g.npub[g.lane] = 0;
+    if (ROLES == 3) {
+      g.ord.oseq[g.lane] = 0;
+      g.ord.otak[g.lane] = 0;
+    }
+  }
+  __syncthreads();
+
+#ifdef VS_TIMING_GENERATOR_ONLY
+  if (role == ROLES - 1) return;
+#endif
+#ifdef VS_TIMING_FILTER_ONLY
+  if (role != ROLES - 1) return;
+#endif
+#ifdef VS_EXP_NOISE_FIRST
+  const int noise_role = 0;
+#else
+  const int noise_role = 1;
+#endif
+#ifdef VS_EXP_NOISE_PRIO
+  if (ROLES == 3 && role == noise_role) __builtin_amdgcn_s_setprio(VS_EXP_NOISE_PRIO);
+#endif
+  if (role == ROLES - 1) vs_filter_wave<ARITH, PRE1, ROLES == 2>(args, g);
+  else if (ROLES == 3 && role == noise_role) vs_noise_wave(args, g);
+  else vs_generator_wave<ROLES == 3>(args, g);
 }
 
 /*
@@ -1776,13 +2010,16 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_
   vs_kernel_fn fn = nullptr;
   unsigned block = VS_WAVE;
   if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
-    if (arith == VS_ARITH_EXACT)
-      fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false>;
-    else
-      fn = (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false>;
-    /* lds_bytes arrives as the bytes of ONE pair (ring + cos rows + gpub/npub); args->ws_pairs
-     * pairs share a workgroup */
-    block = 2 * VS_WAVE * (unsigned)args->ws_pairs;
+    const bool three = args->ws_roles == 3;
+    if (arith == VS_ARITH_EXACT) {
+      if (three) fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 3>;
+      else fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 2> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 2>;
+    } else {
+      fn = three ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 2>;
+    }
+    /* lds_bytes arrives as the bytes of ONE group (ring + cos rows + progress words); args->ws_pairs
+     * groups share a workgroup, args->ws_roles wavefronts serve each */
+    block = (unsigned)args->ws_roles * VS_WAVE * (unsigned)args->ws_pairs;
     lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
   } else if (arith == VS_ARITH_EXACT) {
