@@ -412,11 +412,7 @@ __device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
  * reads the word first and the data second -- no wait for the data stores to come back is needed,
  * only the compiler must not move the accesses across each other (a fence with workgroup scope
  * would add an s_waitcnt lgkmcnt(0), a full LDS round trip, to every noise trip). */
-#ifdef VS_EXP_HWFENCE
-#define VS_LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
-#else
 #define VS_LDS_RELEASE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
-#endif
 
 #ifndef VS_PUB_EVERY
 #define VS_PUB_EVERY 1 /* wave-specialised kernel: the generator publishes its noise progress every N-th trip (power of two) */
@@ -1638,16 +1634,8 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
 #ifdef VS_TIMING_FILTER_ONLY
   if (role != ROLES - 1) return;
 #endif
-#ifdef VS_EXP_NOISE_FIRST
-  const int noise_role = 0;
-#else
-  const int noise_role = 1;
-#endif
-#ifdef VS_EXP_NOISE_PRIO
-  if (ROLES == 3 && role == noise_role) __builtin_amdgcn_s_setprio(VS_EXP_NOISE_PRIO);
-#endif
   if (role == ROLES - 1) vs_filter_wave<ARITH, PRE1, ROLES == 2>(args, g);
-  else if (ROLES == 3 && role == noise_role) vs_noise_wave(args, g);
+  else if (ROLES == 3 && role == 1) vs_noise_wave(args, g);
   else vs_generator_wave<ROLES == 3>(args, g);
 }
 
