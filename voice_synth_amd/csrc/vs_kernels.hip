@@ -236,10 +236,22 @@ __device__ __forceinline__ int vs_round2int(double x)
  * samples) and, when either hits, rounds that super-step again with vs_round2int() -- outputs are
  * not fed back, so nothing else has to be redone.  Three fp64 instructions per sample instead of five.
  */
+__device__ __forceinline__ int vs_round2int_half_down_unclamped(double x) { return (int)ceil(x - 0.5); }
 __device__ __forceinline__ int vs_round2int_half_down(double x)
 {
-  const int v = (int)ceil(x - 0.5);
+  const int v = vs_round2int_half_down_unclamped(x);
   return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
+}
+/* two rounded values, clamped to [-32767, 32767] and packed: V_CVT_PK_I16_I32 saturates to int16,
+ * V_PK_MAX_I16 lifts -32768 to the reference's -32767 (vowel_new.c:423-424) -- two instructions for two
+ * samples instead of two V_MED3_I32 and a V_PERM_B32 */
+typedef short vs_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t vs_clamp_pack16(int lo, int hi)
+{
+  const vs_i16x2 p = __builtin_amdgcn_cvt_pk_i16(lo, hi);
+  const vs_i16x2 floor_ = {(short)-32767, (short)-32767};
+  const vs_i16x2 q = __builtin_elementwise_max(p, floor_);
+  return __builtin_bit_cast(uint32_t, q);
 }
 #define VS_R2I_Q1_HI ((int)0xBC900000) /* high word of -2^-54, as a signed integer */
 
@@ -959,7 +971,7 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
  * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
  * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
  */
-template <int ARITH, int KIND, bool PRE1 = false>
+template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
@@ -997,12 +1009,17 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
     if (whole) {
       vs_u32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+      for (int e = 0; e < 4; ++e)
+        v[e] = PACKED ? vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1])
+                      : vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
       if (store_ok) *(vs_u32x4 *)(orow + n + 8 * k) = v;
     } else {
 #pragma unroll
-      for (int t = 8 * k; t < 8 * k + 8; ++t)
-        if (store_ok && (n + t < N)) orow[n + t] = (int16_t)outv[t];
+      for (int t = 8 * k; t < 8 * k + 8; ++t) {
+        int v = outv[t];
+        if (PACKED) v = (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
+        if (store_ok && (n + t < N)) orow[n + t] = (int16_t)v;
+      }
     }
   };
 
@@ -1049,7 +1066,8 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
        * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
       const double o = PRE1 ? (acc - y1)
                             : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
-      outv[t] = vs_round2int_half_down(o);
+      /* PACKED: the caller does not look at outv[]; the clamp rides on the packing (put8) */
+      outv[t] = PACKED ? vs_round2int_half_down_unclamped(o) : vs_round2int_half_down(o);
       /* rounded HERE: left to itself the compiler keeps all 24 arguments (48 registers) and rounds
        * them behind the quirk test below, where the other branch does not need the results */
       asm volatile("" : "+v"(outv[t]));
@@ -1525,8 +1543,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       int outv[VS_SS];
       vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n, N,
-                                               args.vec_ok != 0, outv, xpre, valid);
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                     N, args.vec_ok != 0, outv, xpre, valid);
       rslot += VS_SS;
       if (rslot >= C) rslot = 0;
       /* the ring reads above precede this store in the LDS queue: the slots are free */
@@ -1557,8 +1575,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
         if (ready) {
           int outv[VS_SS];
           vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                   N, args.vec_ok != 0, outv, xpre);
+          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                         n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
