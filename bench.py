@@ -23,11 +23,17 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   cpu_baseline : the CPU oracle (kind "port", OpenMP over lanes) on this box's host cores, on a
                  bounded sample of the same workload, and next to it the REFERENCE as shipped
                  (oracle/_ref, -O0 as its Makefile builds it, and -O2; one process pair per
-                 utterance through .wav files, all host cores) -- rank 0, N = 1 only;
-  value_with_gather / gather : N > 1 only -- the same synthesis in chunks of 16384 utterances with
-                 every finished chunk travelling to rank 0 over RCCL while the next one is being
-                 synthesised (voice_synth_amd/dist.py::PipelinedGather), timed end to end AFTER
-                 the timed region; `value` itself leaves the PCM sharded.
+                 utterance through .wav files, all host cores, driven by oracle/ref_pipelines) --
+                 rank 0, N = 1 only;
+  other_arith  : the other arithmetic contract (fma when the run is exact), HIP events around each of
+                 10 launches after 3 warm-ups, outside the timed region;
+  config4      : N > 1 only -- BASELINE.json's configuration for the node: 262144 utterances x 44100
+                 samples (22.05 kHz, 2 s) cut over the N ranks; `value` (PCM left sharded),
+                 `roofline_per_gpu`, and `value_with_gather` / `gather`: the same synthesis in chunks of
+                 16384 utterances with every finished chunk travelling to rank 0 over RCCL while the next
+                 one is being synthesised (voice_synth_amd/dist.py::PipelinedGather), timed end to end.
+                 The top-level `value` stays config 3 per GPU (weak scaling), so that the N = 1 point of a
+                 scaling curve is the single-GPU bench line.
 VS_BENCH_REHEARSAL=1|2 (tests only): all ranks share device 0 and talk over gloo, so that the N > 1
 control flow -- and with 2 also the pipelined gather leg, end to end on device tensors -- can be run on
 a one-GPU box (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
@@ -65,6 +71,8 @@ def parse_args():
     ap.add_argument("--arith", choices=["exact", "fma"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the config-4 block (262144 x 44100 over the ranks)")
+    ap.add_argument("--config4-lanes", type=int, default=0, help="N > 1: utterances of the config-4 block (default 262144; tests)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline run time")
     return ap.parse_args()
 
@@ -79,23 +87,56 @@ def _cpu_model():
     return "unknown"
 
 
-def reference_as_shipped(specs, n_samples, opt, workers):
-    """oracle/_ref (the reference's own two programs, Philox random() shim) over `specs`: one
-    process pair per utterance through .wav files in a scratch directory, `workers` pairs in
-    flight -- what `xargs -P $(nproc)` would do with the reference as it ships."""
-    from concurrent.futures import ThreadPoolExecutor
+def reference_as_shipped(specs_fn, n_samples, workers, target_s=6.0):
+    """oracle/_ref (the reference's own two programs, built -O0 as its Makefile does and -O2, Philox
+    random() shim) over the bench workload: one process pair per utterance through .wav files,
+    `workers` worker processes -- what `xargs -P $(nproc)` does with the reference as it ships.
+    Run by oracle/ref_pipelines (C, posix_spawn; no interpreter in the loop): a calibration run, then
+    at least 4096 pipelines sized for about target_s seconds."""
+    import subprocess
+    import tempfile
 
-    from oracle import pyoracle as po
+    helper = os.path.join(ROOT, "oracle", "ref_pipelines")
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    out = {"workers": workers, "cpu_model": _cpu_model(),
+           "how": "oracle/ref_pipelines: per utterance `flowgen_shimmer -o f.wav ...; vowel -i f.wav -o v.wav ...` "
+                  "(posix_spawn, one scratch directory per worker), process start and file I/O included"}
+    if not os.path.exists(helper):
+        out["error"] = "oracle/ref_pipelines is not built"
+        return out
 
-    def one(spec):
-        fa, va, seed = spec
-        return po.run_reference(fa, va, seed, opt=opt)["pcm"]
+    def run(n, suffix, scratch):
+        specs = specs_fn(n)
+        mf = os.path.join(scratch, "manifest.txt")
+        with open(mf, "w") as f:
+            for fa, va, seed in specs:
+                f.write("%d|%s|%s\n" % (seed, " ".join(fa), " ".join(va)))
+        r = subprocess.run([helper, os.path.join(refdir, "flowgen_shimmer" + suffix), os.path.join(refdir, "vowel" + suffix),
+                            mf, str(workers), scratch], capture_output=True, text=True, timeout=600)
+        rec = json.loads(r.stdout.strip().splitlines()[-1])
+        if r.returncode != 0 or rec["failed"]:
+            raise RuntimeError("ref_pipelines: rc %d, %s %s" % (r.returncode, r.stdout.strip(), r.stderr.strip()[:200]))
+        return rec
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        pcms = list(ex.map(one, specs))
-    t = time.perf_counter() - t0
-    return pcms, t
+    for suffix, key in (("", "O0_as_shipped"), ("_O2", "O2")):
+        if not os.path.exists(os.path.join(refdir, "vowel" + suffix)):
+            out[key] = {"error": "oracle/_ref/vowel%s is not built" % suffix}
+            continue
+        try:
+            with tempfile.TemporaryDirectory(prefix="vsrp") as scratch:
+                cal = run(8 * workers, suffix, scratch)
+                n = int(max(4096, min(400000, target_s * cal["pipelines"] / cal["seconds"])))
+                rec = run(n, suffix, scratch)
+            per = rec["pipelines"] / rec["seconds"]
+            out[key] = {"value": round(per * n_samples / 1e6, 2), "unit": "Msamples/s",
+                        "pipelines": rec["pipelines"], "seconds": round(rec["seconds"], 2),
+                        "pipelines_per_s": round(per, 1),
+                        "ms_per_pipeline_per_worker": round(1e3 * workers / per, 3),
+                        "ms_in_flowgen": round(1e3 * rec["process_seconds_flowgen"] / rec["pipelines"], 3),
+                        "ms_in_vowel": round(1e3 * rec["process_seconds_vowel"] / rec["pipelines"], 3)}
+        except Exception as exc:  # pragma: no cover - e.g. a process limit of the box
+            out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    return out
 
 
 def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
@@ -139,20 +180,17 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
                   % (n_lanes, n_samples, t),
     }
     if po.have_reference():
-        # the reference AS SHIPPED: its Makefile passes no -O flag (-O0); -O2 next to it.  One
-        # process pair per utterance, `workers` in flight, >= 4 utterances per worker.
-        workers = max(1, min(host_cores, 64))  # the GPU box caps the processes one command may run
-        specs = specs_fn(4 * workers)
-        shipped = {"workers": workers, "utterances": len(specs), "cpu_model": _cpu_model(),
-                   "how": "oracle/_ref/flowgen_shimmer | file | oracle/_ref/vowel per utterance, process start and file I/O included"}
-        for opt, key in (("", "O0_as_shipped"), ("O2", "O2")):
-            try:
-                pcms, tr = reference_as_shipped(specs, n_samples, opt, workers)
-                shipped[key] = {"value": round(len(specs) * n_samples / tr / 1e6, 2), "unit": "Msamples/s",
-                                "seconds": round(tr, 2),
-                                "matches_port": bool(all(np.array_equal(p, pcm[i]) for i, p in enumerate(pcms[:min(len(pcms), n_lanes)])))}
-            except Exception as exc:  # pragma: no cover - e.g. the -O2 build is absent
-                shipped[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # the reference AS SHIPPED: its Makefile passes no -O flag (-O0); -O2 next to it.  The GPU box
+        # allows 1024 processes per command: a worker and its one child each.
+        workers = max(1, min(host_cores, 256))
+        shipped = reference_as_shipped(specs_fn, n_samples, workers)
+        # the compiled reference and the port agree (a handful of utterances through the Python harness)
+        try:
+            few = specs_fn(4)
+            shipped["matches_port"] = bool(all(
+                np.array_equal(po.run_reference(fa, va, seed)["pcm"], pcm[i]) for i, (fa, va, seed) in enumerate(few)))
+        except Exception as exc:  # pragma: no cover
+            shipped["matches_port"] = "%s: %s" % (type(exc).__name__, exc)
         out["reference_as_shipped"] = shipped
     if gpu_first_lanes is not None:
         # every GPU row the CPU sample covers (the whole batch when the sample is at least as large)
@@ -203,7 +241,6 @@ def main():
 
     import voice_synth_amd as vs
     from voice_synth_amd import configs
-    from voice_synth_amd.dist import PipelinedGather, gather_pcm
 
     # VS_BENCH_REHEARSAL=1 (tests only): all ranks share device 0 and talk over gloo -- the N > 1 control
     # flow (sharded lane keys, barriers, max-over-ranks timing, rank 0's line) on a one-GPU box.  RCCL
@@ -212,7 +249,7 @@ def main():
     if rehearsal:
         local_rank = 0
         if os.environ.get("VS_BENCH_REHEARSAL") == "1":
-            args.no_gather = True
+            args.no_gather = True   # gloo on device tensors: only with VS_BENCH_REHEARSAL=2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
@@ -281,20 +318,23 @@ def main():
     n_check = per_gpu if (world == 1 and not args.no_cpu_baseline) else min(64, per_gpu)
     first_rows = out[:n_check, :n_samples].cpu().numpy() if rank == 0 else None
 
-    # ---- the other arithmetic mode, outside the timed region (3 launches) ----
+    # ---- the other arithmetic mode, outside the timed region: 3 warm-ups, then HIP events around
+    # each of 10 launches, as in the timed region (mean, median and min reported) ----
     other = vs.VS_ARITH_FMA if arith == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
     eng.set_arith(other)
     other_kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
-    launch()
-    torch.cuda.synchronize(dev)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(stream)
     for _ in range(3):
         launch()
-    b.record(stream)
+    torch.cuda.synchronize(dev)
+    oev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in oev:
+        a.record(stream)
+        launch()
+        b.record(stream)
     torch.cuda.synchronize(dev)
     plan.status()
-    other_ms = a.elapsed_time(b) / 3.0
+    other_kern = sorted(a.elapsed_time(b) for a, b in oev)
+    other_ms = sum(other_kern) / len(other_kern)
     eng.set_arith(arith)
 
     result = None
@@ -306,6 +346,8 @@ def main():
         tflops = FLOP_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e12
         valu = None
         sq = _profile_record("pmc_valu.json", key)
+        if sq and kernel_name not in str(sq.get("kernel", "")):
+            sq = None   # the committed counters are of another kernel: no figure rather than a mixed one
         if sq:
             # wave-instructions from the SQ counters of the committed profile of THIS kernel; the
             # duration is this run's.  Issue ceiling of one wavefront per SIMD measured by
@@ -366,7 +408,10 @@ def main():
             },
             "other_arith": {"arith": "fma" if arith == vs.VS_ARITH_EXACT else "exact",
                             "kernel": other_kernel,
+                            "launches": len(other_kern),
                             "kernel_ms_avg": round(other_ms, 4),
+                            "kernel_ms_median": round(other_kern[len(other_kern) // 2], 4),
+                            "kernel_ms_min": round(other_kern[0], 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
             "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
                      "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
@@ -384,101 +429,50 @@ def main():
                                       "rows_checked": cb.get("gpu_rows_checked"),
                                       "tolerance_normalised": 1e-5}
 
-    # ---- N > 1: synthesis WITH delivery of the PCM to rank 0 over RCCL, end to end ----
-    # Runs LAST and under a watchdog: should the exchange ever stall (it cannot be rehearsed with
-    # more than one rank on a one-GPU box), every rank leaves after GATHER_DEADLINE_S and rank 0
-    # still prints the line, with the stall reported instead of the gather figures.
-    gather = None
-    value_with_gather = None
-    printed = threading.Event()
+    # ---- N > 1: the configuration BASELINE.json names for the node -- config 4, 262144 utterances x
+    # 44100 samples cut over the N ranks -- timed like the steps above, and then the same synthesis
+    # WITH delivery of the PCM to rank 0 over RCCL, end to end.  Runs LAST and under a watchdog:
+    # should the exchange ever stall (it cannot be rehearsed with more than one rank on a one-GPU
+    # box), every rank leaves after GATHER_DEADLINE_S with a NON-ZERO exit code and rank 0 still
+    # prints the line, with the stall reported instead of the figures.
+    out_lock = threading.Lock()
+    printed = [False]
+    extra = {}
 
     def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
-            if value_with_gather is not None:
-                result["value_with_gather"] = round(value_with_gather, 1)
-            if gather:
-                result["gather"] = gather
-            print(json.dumps(result), flush=True)
+        with out_lock:
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                result.update(extra)
+                print(json.dumps(result), flush=True)
+
+    leg_done = threading.Event()
 
     def watchdog():
         if not leg_done.wait(GATHER_DEADLINE_S):
-            if rank == 0 and not printed.is_set():
-                printed.set()
-                result["gather"] = {"error": "no completion within %d s" % GATHER_DEADLINE_S, "included_in_value": False}
-                print(json.dumps(result), flush=True)
-            os._exit(0)
+            with out_lock:
+                if rank == 0 and not printed[0]:
+                    printed[0] = True
+                    result["config4"] = dict(extra.get("config4") or {}, error="no completion within %d s" % GATHER_DEADLINE_S)
+                    print(json.dumps(result), flush=True)
+            os._exit(3)   # a stalled exchange is a finding, not a success
 
-    leg_done = threading.Event()
-    if world > 1 and not args.no_gather:
+    if world > 1 and not args.no_config4:
         threading.Thread(target=watchdog, daemon=True).start()
-        # optional leg: it must never cost the benchmark line, so failures are reported
+        del out
+        torch.cuda.empty_cache()
         try:
-            # every rank must take the same decision, or the peers would wait for a root that
-            # gave up: rank 0 checks that the gathered PCM fits, the verdict is all-reduced
-            need = 2 * per_gpu * world * n_samples * 2 + (2 << 30)   # the gathered PCM, twice (overlapped + comparison)
-            fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0],
-                                dtype=torch.int32, device=dev)
-            dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-            if int(fits.item()) == 0:
-                raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
-            del out
-            torch.cuda.empty_cache()
-            # chunk plans of this rank (host work, outside the timed part)
-            pg = PipelinedGather(per_gpu * world, n_samples, GATHER_CHUNK, dev)
-            plans = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), n_samples)
-                     for a_, b_ in pg.edges]
-
-            def launch_chunk(kk, tensor):
-                plans[kk].launch(vs.VS_KIND_SYNTH, tensor.data_ptr(), out_pitch=n_samples)
-
-            pg.run(launch_chunk)          # warm-up pass (RCCL connections, code objects)
-            sync_all()
-            g0 = time.perf_counter()
-            full_pcm = pg.run(launch_chunk)
-            sync_all()
-            g = time.perf_counter() - g0
-            gt = torch.tensor([g], dtype=torch.float64, device=dev)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            g = float(gt.item())
-            for p_ in plans:
-                p_.status()
-            nbytes = per_gpu * (world - 1) * n_samples * 2
-            value_with_gather = samples_per_step / g / 1e6
-            gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
-                      "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
-                      "ingress_GB/s": round(nbytes / g / 1e9, 1), "included_in_value": False,
-                      "transport": "%s send/recv, one grouped receive per chunk on the root (torch.distributed)"
-                                   % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend())}
-            # the un-overlapped comparison: the same chunks, then one gather behind them
-            sync_all()
-            g0 = time.perf_counter()
-            for kk, tns in enumerate(pg.chunks):
-                launch_chunk(kk, tns)
-            torch.cuda.synchronize(dev)
-            again = gather_pcm(pg.base, per_gpu * world, dst=0)
-            sync_all()
-            g2 = time.perf_counter() - g0
-            gt = torch.tensor([g2], dtype=torch.float64, device=dev)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            gather["ms_compute_then_gather"] = round(float(gt.item()) * 1e3, 3)
-            if rank == 0:
-                gather["equals_unoverlapped_gather"] = bool(torch.equal(again, full_pcm))
-            del again, full_pcm
-            for p_ in plans:
-                p_.close()
-        except Exception as exc:  # pragma: no cover - depends on the node's RCCL
-            gather = {"error": "%s: %s" % (type(exc).__name__, exc), "included_in_value": False}
-
+            extra["config4"] = config4_block(args, eng, dev, stream, rank, world, cus, sync_all)
+        except Exception as exc:  # pragma: no cover - depends on the node
+            extra["config4"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     leg_done.set()
     emit()
 
     if use_dist:
-        # the line is out; a peer that left early (its own gather leg failed) must not hold the
-        # others in the closing barrier
+        # the line is out; a peer that left early must not hold the others in the closing barrier
         def leave():
             time.sleep(TEARDOWN_DEADLINE_S)
-            os._exit(0)
+            os._exit(4)
         threading.Thread(target=leave, daemon=True).start()
 
     plan.close()
@@ -486,6 +480,117 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def config4_block(args, eng, dev, stream, rank, world, cus, sync_all):
+    """BASELINE.json configs[3]: 262144 utterances, mixed vowels, 22.05 kHz, 2 s, cut over the ranks in
+    contiguous lane blocks (voice_synth_amd.dist.shard_range, the same cut vs_node_* makes in C), lane
+    keys from the global lane index.  `value`: K launches, PCM left sharded, as the headline figure;
+    `value_with_gather`: the same synthesis in chunks with every finished chunk travelling to rank 0
+    while the next one is being synthesised (PipelinedGather), timed end to end."""
+    import torch
+    import torch.distributed as dist
+
+    import voice_synth_amd as vs
+    from voice_synth_amd import configs
+    from voice_synth_amd.dist import PipelinedGather, gather_pcm, shard_range
+
+    total = args.config4_lanes or 262144
+    lo, hi = shard_range(total, rank, world)
+    per = hi - lo
+    specs, fs, dur, label = configs.config_specs(4, per, lane0=lo)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    pitch = (ns + 7) & ~7
+    plan = eng.plan(lanes, ns)
+    kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
+    out = torch.empty((per, pitch), dtype=torch.int16, device=dev)
+    steps = max(2, min(args.steps, 5))
+
+    def launch():
+        plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+
+    for _ in range(2):
+        launch()
+    sync_all()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        launch()
+        b.record(stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    plan.status()
+    kern = sum(a.elapsed_time(b) for a, b in ev) / steps
+    t = torch.tensor([elapsed, kern], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern = float(t[0].item()), float(t[1].item())
+    achieved = ALGO_BYTES_PER_SAMPLE * per * ns / (kern * 1e-3) / 1e9
+    block = {"workload": label, "utterances": total, "utterances_per_gpu": per, "samples_per_utterance": ns,
+             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+             "value": round(total * ns * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+             "roofline_per_gpu": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(achieved / HBM_PEAK_GBPS, 4), "kernel": kernel,
+                                  "kernel_ms_avg": round(kern, 4)}}
+    del out
+    plan.close()
+    torch.cuda.empty_cache()
+    if args.no_gather:
+        return block
+
+    # ---- with delivery to rank 0 ----
+    # every rank must take the same decision, or the peers would wait for a root that gave up: rank 0
+    # checks that the gathered PCM fits (twice: overlapped + comparison), the verdict is all-reduced
+    need = 2 * total * ns * 2 + (2 << 30)
+    fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(fits, op=dist.ReduceOp.MIN)
+    if int(fits.item()) == 0:
+        block["gather"] = {"error": "rank 0 has no room for %d bytes of gathered PCM" % need}
+        return block
+    pg = PipelinedGather(total, ns, GATHER_CHUNK, dev)
+    plans = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), ns) for a_, b_ in pg.edges]
+
+    def launch_chunk(kk, tensor):
+        plans[kk].launch(vs.VS_KIND_SYNTH, tensor.data_ptr(), out_pitch=ns)
+
+    pg.run(launch_chunk)          # warm-up pass (RCCL connections, code objects)
+    sync_all()
+    g0 = time.perf_counter()
+    full_pcm = pg.run(launch_chunk)
+    sync_all()
+    g = time.perf_counter() - g0
+    gt = torch.tensor([g], dtype=torch.float64, device=dev)
+    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+    g = float(gt.item())
+    for p_ in plans:
+        p_.status()
+    nbytes = (total - (shard_range(total, 0, world)[1] - shard_range(total, 0, world)[0])) * ns * 2
+    block["value_with_gather"] = round(total * ns / g / 1e6, 1)
+    gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
+              "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
+              "ingress_GB/s": round(nbytes / g / 1e9, 1),
+              "backend": dist.get_backend(),
+              "transport": "torch.distributed send/recv (backend above; nccl = RCCL over xGMI), one grouped receive per chunk on the root"}
+    # the un-overlapped comparison: the same chunks, then one gather behind them
+    sync_all()
+    g0 = time.perf_counter()
+    for kk, tns in enumerate(pg.chunks):
+        launch_chunk(kk, tns)
+    torch.cuda.synchronize(dev)
+    again = gather_pcm(pg.base, total, dst=0)
+    sync_all()
+    g2 = time.perf_counter() - g0
+    gt = torch.tensor([g2], dtype=torch.float64, device=dev)
+    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+    gather["ms_compute_then_gather"] = round(float(gt.item()) * 1e3, 3)
+    if rank == 0:
+        gather["equals_unoverlapped_gather"] = bool(torch.equal(again, full_pcm))
+    del again, full_pcm
+    for p_ in plans:
+        p_.close()
+    block["gather"] = gather
+    return block
 
 
 if __name__ == "__main__":

@@ -36,9 +36,14 @@ def test_bench_single_process_small():
     d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["cpu_baseline"]["gpu_rows_checked"] >= 1 and d["cpu_baseline"]["gpu_mismatched_samples"] == 0
+    assert d["other_arith"]["launches"] >= 10 and d["other_arith"]["kernel_ms_min"] <= d["other_arith"]["kernel_ms_median"]
     ref = d["cpu_baseline"].get("reference_as_shipped")
     if ref:                                                  # oracle/_ref travels to the GPU box
-        assert ref["O0_as_shipped"]["matches_port"] and ref["O2"]["matches_port"]
+        assert ref["matches_port"] is True
+        for key in ("O0_as_shipped", "O2"):
+            assert ref[key]["pipelines"] >= 4096 and ref[key]["value"] > 0, ref[key]
+            # the two programs account for the workers' time (no launcher in the loop)
+            assert ref[key]["ms_in_flowgen"] + ref[key]["ms_in_vowel"] > 0.8 * ref[key]["ms_per_pipeline_per_worker"]
 
 
 def _free_port():
@@ -65,7 +70,7 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     rank synthesises its own block of the global batch; rank 0 prints the whole-job line."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--lanes", "4096", "--steps", "3",
-           "--warmup", "1"]
+           "--warmup", "1", "--config4-lanes", "1000"]
     out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600, env=dict(os.environ, VS_BENCH_REHEARSAL="1"))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
@@ -76,3 +81,28 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     # whole-job value = the units of both ranks over the slowest rank's time
     assert abs(d["value"] - 2 * 4096 * 16000 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) / d["value"] < 0.01
     assert "cpu_baseline" not in d              # rank 0 at N = 1 only
+    # the configuration BASELINE.json names for N > 1 rides along: config 4 cut over the ranks
+    c4 = d["config4"]
+    assert "error" not in c4, c4
+    assert c4["utterances"] == 1000 and c4["utterances_per_gpu"] == 500 and c4["samples_per_utterance"] == 44100
+    assert c4["value"] > 0 and c4["roofline_per_gpu"]["kernel"].startswith("vs_synth")
+    assert "gather" not in c4                   # VS_BENCH_REHEARSAL=1: no exchange of device tensors
+
+
+def test_bench_three_ranks_rehearsal_with_the_gather_leg():
+    """VS_BENCH_REHEARSAL=2: three ranks on device 0 over gloo, the config-4 block WITH its pipelined gather
+    (ragged: 1000 utterances over three ranks, chunks of 16384 -> one chunk each): the gathered PCM must
+    equal the un-overlapped gather.  What this cannot show is RCCL itself."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--lanes", "2048", "--steps", "2",
+           "--warmup", "1", "--config4-lanes", "1000"]
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=900, env=dict(os.environ, VS_BENCH_REHEARSAL="2"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    d = json.loads(lines[-1])
+    c4 = d["config4"]
+    assert d["n_gpus"] == 3 and "error" not in c4, c4
+    assert c4["utterances_per_gpu"] == 334       # rank 0's block of 1000 over 3
+    g = c4["gather"]
+    assert g["backend"] == "gloo" and g["overlapped"] is True and g["equals_unoverlapped_gather"] is True
+    assert g["bytes_into_rank0"] == (1000 - 334) * 44100 * 2 and c4["value_with_gather"] > 0

@@ -47,8 +47,11 @@ def test_shard_ranges_are_contiguous_blocks():
     try:
         edges = [node.shard_range(262144, s) for s in range(8)]
         assert edges == [(s * 32768, (s + 1) * 32768) for s in range(8)]     # BASELINE config 4
-        edges = [node.shard_range(10, s) for s in range(8)]
-        assert edges[0] == (0, 2) and edges[4] == (8, 10) and edges[5] == (10, 10)
+        # ragged: blocks differ by at most one lane, exactly as the one-process-per-GPU path cuts them
+        from voice_synth_amd.dist import shard_range
+        for n in (10, 3, 65537, 262143):
+            assert [node.shard_range(n, s) for s in range(8)] == [shard_range(n, s, 8) for s in range(8)]
+        assert node.shard_range(10, 0) == (0, 2) and node.shard_range(10, 2) == (4, 5) and node.shard_range(10, 7) == (9, 10)
     finally:
         node.close()
 

@@ -124,12 +124,13 @@ extern "C" int vs_node_set_arith(vs_node *nd, int arith)
   return VS_OK;
 }
 
-/* lanes [lo, hi) of shard s: contiguous blocks of ceil(n / shards) */
+/* lanes [lo, hi) of shard s: contiguous blocks that differ by at most one lane -- the same cut as
+ * voice_synth_amd/dist.py::shard_range makes for the one-process-per-GPU path */
 static void shard_range(size_t n_lanes, size_t shards, size_t s, size_t *lo, size_t *hi)
 {
-  const size_t per = (n_lanes + shards - 1) / shards;
-  *lo = std::min(n_lanes, s * per);
-  *hi = std::min(n_lanes, *lo + per);
+  const size_t base = n_lanes / shards, rem = n_lanes % shards;
+  *lo = s * base + std::min(s, rem);
+  *hi = *lo + base + (s < rem ? 1 : 0);
 }
 
 extern "C" int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard, size_t *lo, size_t *hi)

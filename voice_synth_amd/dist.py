@@ -12,7 +12,8 @@ import torch.distributed as dist
 
 
 def shard_range(n_lanes, rank, world):
-    """Contiguous lane block [lo, hi) of `rank`; blocks differ by at most one lane."""
+    """Contiguous lane block [lo, hi) of `rank`; blocks differ by at most one lane.  The same cut as
+    vs_node_shard_range() in csrc/vs_node.hip (tests/test_sharding_gloo.py holds them together)."""
     base, rem = divmod(int(n_lanes), int(world))
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
@@ -109,6 +110,11 @@ class PipelinedGather:
                 continue
             if self.rank != self.dst:
                 if self.cuda:
+                    if dist.get_backend() != "nccl":
+                        # gloo reads a device tensor from the host and knows nothing of streams: the
+                        # chunk must be complete before it is handed over (rehearsal runs only; with
+                        # RCCL the send is enqueued behind the event on the side stream)
+                        ev.synchronize()
                     with torch.cuda.stream(self.comm_stream):
                         self.comm_stream.wait_event(ev)
                         work.append(dist.isend(self.chunks[k], self.dst))
