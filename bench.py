@@ -87,7 +87,16 @@ def _cpu_model():
     return "unknown"
 
 
-def reference_as_shipped(specs_fn, n_samples, workers, target_s=6.0):
+def _cpu_quota():
+    """CPU share of this container in cores (cgroup v2 cpu.max), None when unlimited or unknown"""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if quota == "max" else round(float(quota) / float(period), 2)
+    except Exception:
+        return None
+
+
+def reference_as_shipped(specs_fn, n_samples, max_workers, target_s=6.0):
     """oracle/_ref (the reference's own two programs, built -O0 as its Makefile does and -O2, Philox
     random() shim) over the bench workload: one process pair per utterance through .wav files,
     `workers` worker processes -- what `xargs -P $(nproc)` does with the reference as it ships.
@@ -98,14 +107,14 @@ def reference_as_shipped(specs_fn, n_samples, workers, target_s=6.0):
 
     helper = os.path.join(ROOT, "oracle", "ref_pipelines")
     refdir = os.path.join(ROOT, "oracle", "_ref")
-    out = {"workers": workers, "cpu_model": _cpu_model(),
+    out = {"cpu_model": _cpu_model(), "cpu_quota_cores": _cpu_quota(),
            "how": "oracle/ref_pipelines: per utterance `flowgen_shimmer -o f.wav ...; vowel -i f.wav -o v.wav ...` "
                   "(posix_spawn, one scratch directory per worker), process start and file I/O included"}
     if not os.path.exists(helper):
         out["error"] = "oracle/ref_pipelines is not built"
         return out
 
-    def run(n, suffix, scratch):
+    def run(n, suffix, scratch, workers):
         specs = specs_fn(n)
         mf = os.path.join(scratch, "manifest.txt")
         with open(mf, "w") as f:
@@ -124,16 +133,26 @@ def reference_as_shipped(specs_fn, n_samples, workers, target_s=6.0):
             continue
         try:
             with tempfile.TemporaryDirectory(prefix="vsrp") as scratch:
-                cal = run(8 * workers, suffix, scratch)
-                n = int(max(4096, min(400000, target_s * cal["pipelines"] / cal["seconds"])))
-                rec = run(n, suffix, scratch)
+                # how many workers this box can feed: the affinity mask of a container says little about
+                # its CPU share (a one-GPU box reports 256 CPUs and peaks at 16 workers), so take the
+                # best of a short sweep
+                sweep = {}
+                w = max_workers
+                while w >= 4:
+                    cal = run(8 * w, suffix, scratch, w)
+                    sweep[w] = round(cal["pipelines"] / cal["seconds"], 1)
+                    w //= 2
+                workers = max(sweep, key=sweep.get)
+                n = int(max(4096, min(400000, target_s * sweep[workers])))
+                rec = run(n, suffix, scratch, workers)
             per = rec["pipelines"] / rec["seconds"]
-            out[key] = {"value": round(per * n_samples / 1e6, 2), "unit": "Msamples/s",
+            out[key] = {"value": round(per * n_samples / 1e6, 2), "unit": "Msamples/s", "workers": workers,
                         "pipelines": rec["pipelines"], "seconds": round(rec["seconds"], 2),
                         "pipelines_per_s": round(per, 1),
                         "ms_per_pipeline_per_worker": round(1e3 * workers / per, 3),
                         "ms_in_flowgen": round(1e3 * rec["process_seconds_flowgen"] / rec["pipelines"], 3),
-                        "ms_in_vowel": round(1e3 * rec["process_seconds_vowel"] / rec["pipelines"], 3)}
+                        "ms_in_vowel": round(1e3 * rec["process_seconds_vowel"] / rec["pipelines"], 3),
+                        "pipelines_per_s_by_workers": {str(k): v for k, v in sorted(sweep.items())}}
         except Exception as exc:  # pragma: no cover - e.g. a process limit of the box
             out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
@@ -174,6 +193,7 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         "value": round(n_lanes * n_samples / t / 1e6, 2),
         "unit": "Msamples/s",
         "cores": cores,
+        "cpu_quota_cores": _cpu_quota(),
         "kind": "port",
         "cpu_model": _cpu_model(),
         "sample": "%d utterances x %d samples of the same workload (first lanes), %.1f s, OpenMP over lanes"

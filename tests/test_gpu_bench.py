@@ -44,6 +44,7 @@ def test_bench_single_process_small():
             assert ref[key]["pipelines"] >= 4096 and ref[key]["value"] > 0, ref[key]
             # the two programs account for the workers' time (no launcher in the loop)
             assert ref[key]["ms_in_flowgen"] + ref[key]["ms_in_vowel"] > 0.8 * ref[key]["ms_per_pipeline_per_worker"]
+            assert ref[key]["workers"] >= 4
 
 
 def _free_port():
