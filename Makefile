@@ -42,7 +42,7 @@ $(CSRC)/vs_node.o: $(CSRC)/vs_node.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
 
@@ -67,10 +67,10 @@ diag: $(LIBDIR)/libvoicesynth_diag.so
 $(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
 $(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 # A/B variants of the library for same-box comparisons (tools/gpu_ab.sh):
 #   make variant NAME=sleep2 DEFS="-DVS_POLL_SLEEP=2"   ->  lib/libvoicesynth_sleep2.so   (select with VS_LIB)
 variant: $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels.hip
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread -ldl

@@ -301,7 +301,7 @@ int vs_filter(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_sample
 
 /* Utterances are independent (all carried state of the reference is per utterance:
  * flowgen_shimmer.c:121-122, vowel_new.c:90), so a batch shards as contiguous blocks of lanes,
- * block s = lanes [s*ceil(n/S), (s+1)*ceil(n/S)), with no data-path collective; a lane's draws
+ * block s of S (blocks differ by at most one lane, vs_node_shard_range), with no data-path collective; a lane's draws
  * are keyed by the seed in its own record, so S shards give byte for byte what one device
  * gives.  devices[] lists one device per shard; a device may appear more than once ("logical
  * shards": how the N-device path is exercised on one GPU).  devices[0] is the root.  One
@@ -313,6 +313,24 @@ int vs_node_shards(const vs_node *node);
 int vs_node_ctx(vs_node *node, int shard, vs_ctx **ctx); /* e.g. for vs_ctx_set_tuning */
 int vs_node_set_arith(vs_node *node, int arith);
 int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *lo, size_t *hi);
+/* How vs_node_synth_gather moves a finished chunk into the root's memory.
+ *   VS_NODE_TRANSPORT_PEER (default): peer DMA, one copy stream per shard.
+ *   VS_NODE_TRANSPORT_RCCL: ncclSend / ncclRecv on ONE RCCL communicator over the node's devices,
+ *     created here and owned by the node (librccl is opened with dlopen at this call).  Needs every
+ *     shard on a device of its own (VS_ERR_UNSUPPORTED otherwise, or when librccl is not there) and a
+ *     packed root buffer (root_pitch == n_samples).
+ * vs_node_link(): how shard's PCM reaches the root -- VS_NODE_LINK_SELF (same device, in place),
+ * _PEER (peer DMA), _STAGED (no peer access between the two devices: the copies go through host
+ * memory), _RCCL.  vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call. */
+#define VS_NODE_TRANSPORT_PEER 0
+#define VS_NODE_TRANSPORT_RCCL 1
+#define VS_NODE_LINK_SELF 0
+#define VS_NODE_LINK_PEER 1
+#define VS_NODE_LINK_STAGED 2
+#define VS_NODE_LINK_RCCL 3
+int vs_node_set_transport(vs_node *node, int transport);
+int vs_node_link(const vs_node *node, int shard);
+int vs_node_last_rccl_error(const vs_node *node);
 /* Synthesis with the final PCM gathered into the ROOT device's memory (root_dev: int16
  * [n_lanes][root_pitch] on devices[0]).  Every shard works through its block in chunks of 16384
  * utterances; with VS_NODE_OVERLAP a finished chunk travels to its rows of root_dev by a peer

@@ -135,3 +135,14 @@ def test_vs_bench_runs_from_plain_c():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["utterances_per_gpu"] == 3000 and d["value"] > 100
+    assert d["links"] == ["self", "self"]
+    # host code in C + RCCL gather, as far as one device goes: a one-rank communicator owned by the node
+    r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "2", "--warmup", "1", "--gpus", "1", "--rccl"],
+                       capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["value"] > 100
+    # ... and logical shards of one device are refused, loudly
+    r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "1", "--warmup", "0", "--gpus", "2", "--rccl"],
+                       capture_output=True, timeout=300, env=dict(os.environ, VS_DEVICES="0,0"))
+    assert r.returncode != 0 and b"RCCL transport" in r.stderr

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import voice_synth_amd as vs
-from voice_synth_amd import configs
+from voice_synth_amd import _ffi, configs
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -48,7 +48,7 @@ def test_shard_ranges_are_contiguous_blocks():
         edges = [node.shard_range(262144, s) for s in range(8)]
         assert edges == [(s * 32768, (s + 1) * 32768) for s in range(8)]     # BASELINE config 4
         # ragged: blocks differ by at most one lane, exactly as the one-process-per-GPU path cuts them
-        from voice_synth_amd.dist import shard_range
+        from voice_synth_amd.configs import shard_range
         for n in (10, 3, 65537, 262143):
             assert [node.shard_range(n, s) for s in range(8)] == [shard_range(n, s, 8) for s in range(8)]
         assert node.shard_range(10, 0) == (0, 2) and node.shard_range(10, 2) == (4, 5) and node.shard_range(10, 7) == (9, 10)
@@ -89,3 +89,36 @@ def test_more_shards_than_lanes(engine):
     finally:
         node.close()
         engine.dev_free(root)
+
+
+def test_links_and_the_rccl_transport_on_one_device(engine, batch):
+    """What one GPU can show of the RCCL transport: the node opens librccl, creates a communicator of its
+    own (one rank), gathers through that code path, and gives the communicator back; logical shards of one
+    device are refused (RCCL puts one rank on one device), and a pitched root buffer too (RCCL messages
+    are contiguous).  Sends and receives between devices stay unexercised until a multi-GPU node runs
+    them."""
+    lanes, ns, want = batch
+    node = vs.Node([0])
+    try:
+        assert node.link(0) == "self"
+        node.set_transport(vs.Node.TRANSPORT_RCCL)
+        root = engine.dev_alloc(len(lanes) * ns * 2)
+        try:
+            node.synth_gather(lanes, ns, root, ns)
+            assert np.array_equal(engine.dev_download(root, (len(lanes), ns), np.int16), want)
+            with pytest.raises(vs.VsError) as e:
+                node.synth_gather(lanes, ns, root, ns + 8)
+            assert e.value.code == _ffi.VS_ERR_UNSUPPORTED
+        finally:
+            engine.dev_free(root)
+        node.set_transport(vs.Node.TRANSPORT_PEER)
+    finally:
+        node.close()
+    node = vs.Node([0, 0, 0])
+    try:
+        assert [node.link(s) for s in range(3)] == ["self", "self", "self"]
+        with pytest.raises(vs.VsError) as e:
+            node.set_transport(vs.Node.TRANSPORT_RCCL)
+        assert e.value.code == _ffi.VS_ERR_UNSUPPORTED
+    finally:
+        node.close()

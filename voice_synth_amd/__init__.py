@@ -319,6 +319,20 @@ class Node:
         except Exception:
             pass
 
+    TRANSPORT_PEER, TRANSPORT_RCCL = 0, 1
+    LINKS = {0: "self", 1: "peer", 2: "staged", 3: "rccl"}
+
+    def set_transport(self, transport):
+        """vs_node_set_transport(): peer DMA (default) or one RCCL communicator owned by the node"""
+        check(self._lib.vs_node_set_transport(self._node, int(transport)), "vs_node_set_transport")
+
+    def link(self, shard):
+        """how the shard's PCM reaches the root: 'self', 'peer', 'staged' (through host memory), 'rccl'"""
+        v = self._lib.vs_node_link(self._node, int(shard))
+        if v < 0:
+            raise VsError(v, "vs_node_link")
+        return self.LINKS[v]
+
     def shard_range(self, n_lanes, shard):
         lo, hi = C.c_size_t(), C.c_size_t()
         check(self._lib.vs_node_shard_range(self._node, n_lanes, shard, C.byref(lo), C.byref(hi)), "vs_node_shard_range")

@@ -1,7 +1,7 @@
 /*
  * vs_bench -- the throughput of the fused source->filter path from plain C, no Python:
  *
- *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G]
+ *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl]]
  *
  * Workload: BASELINE.json configs[2] -- N utterances (default 65536), vowel table "12467"[lane % 5],
  * 16 kHz, 1 s, jitter 1 %, shimmer 0.5 dB (-s 5.76), glottal noise 20 dB, lane key = 1 + lane --
@@ -12,7 +12,9 @@
  * --gpus G times vs_node_synth_gather(): N utterances PER DEVICE (weak scaling, like bench.py),
  * contiguous blocks over devices 0..G-1 (or the ordinals in VS_DEVICES, e.g. "0,0" = two logical
  * shards of one device), every finished chunk copied into device 0's memory behind the synthesis
- * of the next one; the line then also carries the slowest shard's compute time.
+ * of the next one; the line then also carries the slowest shard's compute time and how every
+ * shard reaches the root ("links").  --rccl: the chunks travel by ncclSend / ncclRecv on a communicator
+ * the node object owns (vs_node_set_transport) instead of peer DMA -- host code in C, RCCL gather.
  * One line of JSON on stdout.  bench.py remains the driver's benchmark; this is the same
  * measurement for a maintainer who only has the C side.
  */
@@ -30,7 +32,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
   size_t n_lanes = 65536;
-  int steps = 20, warmup = 5, host = 0, gpus = 0;
+  int steps = 20, warmup = 5, host = 0, gpus = 0, use_rccl = 0;
   const char *arith = "exact";
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--lanes") && i + 1 < argc) n_lanes = (size_t)strtoull(argv[++i], NULL, 0);
@@ -39,8 +41,9 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "--arith") && i + 1 < argc) arith = argv[++i];
     else if (!strcmp(argv[i], "--host")) host = 1;
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+    else if (!strcmp(argv[i], "--rccl")) use_rccl = 1;
     else {
-      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G]\n");
+      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl]]\n");
       return 1;
     }
   }
@@ -84,6 +87,16 @@ int main(int argc, char **argv)
     void *out = NULL;
     double total_ms = 0.0, shard_ms = 0.0, sum_ms = 0.0, worst_shard = 0.0;
     if (rc == VS_OK && !strcmp(arith, "fma")) rc = vs_node_set_arith(node, VS_ARITH_FMA);
+    if (rc == VS_OK && use_rccl) {
+      rc = vs_node_set_transport(node, VS_NODE_TRANSPORT_RCCL);
+      if (rc != VS_OK) fprintf(stderr, "vs_bench: RCCL transport: %s (ncclResult %d)\n", vs_strerror(rc), vs_node_last_rccl_error(node));
+    }
+    char links[64 * 8 + 4] = "";
+    for (int d = 0; rc == VS_OK && d < gpus; d++) {
+      static const char *const names[] = {"self", "peer", "staged", "rccl"};
+      const int l = vs_node_link(node, d);
+      snprintf(links + strlen(links), sizeof(links) - strlen(links), "%s\"%s\"", d ? ", " : "", (l >= 0 && l < 4) ? names[l] : "?");
+    }
     if (rc == VS_OK) rc = vs_node_ctx(node, 0, &root);
     if (rc == VS_OK) rc = vs_dev_alloc(root, n_lanes * n_samples * sizeof(int16_t), &out);
     for (int k = 0; rc == VS_OK && k < warmup + steps; k++) {
@@ -98,9 +111,9 @@ int main(int argc, char **argv)
       printf("{\"metric\": \"synthesised Msamples/s (whole node), PCM gathered into device %d\", \"value\": %.1f, "
              "\"unit\": \"Msamples/s\", \"n_gpus\": %d, \"ms_per_step\": %.4f, \"slowest_shard_compute_ms\": %.4f, "
              "\"steps\": %d, \"warmup\": %d, \"utterances_per_gpu\": %zu, \"samples_per_utterance\": %llu, "
-             "\"arith\": \"%s\", \"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
+             "\"arith\": \"%s\", \"links\": [%s], \"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
              devs[0], (double)n_lanes * (double)n_samples * steps / (sum_ms * 1e-3) / 1e6, gpus, sum_ms / steps, worst_shard,
-             steps, warmup, per_gpu, (unsigned long long)n_samples, arith);
+             steps, warmup, per_gpu, (unsigned long long)n_samples, arith, links);
     if (out) vs_dev_free(root, out);
     vs_node_destroy(node);
     free(lanes);

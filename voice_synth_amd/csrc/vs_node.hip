@@ -21,10 +21,22 @@
  * A device may appear several times in the device list ("logical shards"): that is how the
  * N-device path is tested on a box with one GPU.
  *
+ * Transport of the gather (vs_node_set_transport):
+ *   VS_NODE_TRANSPORT_PEER  peer DMA as above (the default).  A shard whose device cannot reach the
+ *                           root by peer access is reported as VS_NODE_LINK_STAGED by vs_node_link():
+ *                           the runtime then carries its copies through host memory.
+ *   VS_NODE_TRANSPORT_RCCL  one RCCL communicator over the node's (distinct) devices, owned by the
+ *                           node object: a finished chunk leaves by ncclSend on the shard's copy
+ *                           stream, the root posts the matching ncclRecv of every peer's chunk k as
+ *                           one group, each on the stream of that peer's link -- point-to-point over
+ *                           xGMI, no ring.  librccl is opened with dlopen() when this transport is
+ *                           chosen, so that the two drop-in programs do not pay for loading it.
+ *
  * One host thread per shard (a vs_ctx is used by one thread at a time).  The multi-PROCESS form
  * of the same scheme -- one rank per GPU under torch.distributed.run, RCCL send/recv of the
  * chunks -- is what bench.py --gpus N runs; see voice_synth_amd/dist.py.
  */
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -38,11 +50,31 @@
 
 #define VS_NODE_CHUNK 16384
 
+/* the handful of RCCL entry points the gather uses, resolved from librccl at run time (the types are
+ * RCCL's: ncclComm_t is an opaque pointer, ncclResult_t and ncclDataType_t are ints, ncclInt8 == 0) */
+typedef void *vs_nccl_comm;
+struct VsRccl {
+  void *lib;
+  int (*CommInitAll)(vs_nccl_comm *, int, const int *);
+  int (*CommDestroy)(vs_nccl_comm);
+  int (*Send)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t);
+  int (*Recv)(void *, size_t, int, int, vs_nccl_comm, hipStream_t);
+  int (*GroupStart)(void);
+  int (*GroupEnd)(void);
+};
+#define VS_NCCL_INT8 0
+
 struct vs_node {
   std::vector<vs_ctx *> ctx;   /* one per shard */
   std::vector<int> device;
   std::vector<hipStream_t> compute, copy;
   std::vector<hipEvent_t> ev_done[2], ev_copied[2];
+  std::vector<int> link;       /* VS_NODE_LINK_* of every shard */
+  int transport;               /* VS_NODE_TRANSPORT_* */
+  VsRccl rccl;
+  std::vector<vs_nccl_comm> comm;      /* one per shard (rank = shard), RCCL transport only */
+  std::vector<hipStream_t> recv;       /* on the root device: one stream per peer link */
+  int last_rccl_error;
 };
 
 extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
@@ -51,6 +83,9 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
   *out = nullptr;
   vs_node *nd = new (std::nothrow) vs_node();
   if (!nd) return VS_ERR_NOMEM;
+  nd->transport = VS_NODE_TRANSPORT_PEER;
+  memset(&nd->rccl, 0, sizeof(nd->rccl));
+  nd->last_rccl_error = 0;
   int rc = VS_OK;
   for (int s = 0; s < n_shards && rc == VS_OK; s++) {
     vs_ctx *c = nullptr;
@@ -71,15 +106,20 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
     nd->ev_copied[0].push_back(e[2]);
     nd->ev_copied[1].push_back(e[3]);
     if (he != hipSuccess) rc = VS_ERR_HIP;
-    /* the root must be reachable by peer DMA from every other device */
+    /* how this shard's PCM reaches the root: in place, by peer DMA, or -- when the device cannot
+     * reach the root by peer access -- through host memory, which vs_node_link() says out loud */
+    int link = VS_NODE_LINK_SELF;
     if (rc == VS_OK && devices[s] != devices[0]) {
       int can = 0;
+      link = VS_NODE_LINK_STAGED;
       if (hipDeviceCanAccessPeer(&can, devices[s], devices[0]) == hipSuccess && can) {
         he = hipDeviceEnablePeerAccess(devices[0], 0);
         if (he != hipSuccess && he != hipErrorPeerAccessAlreadyEnabled) rc = VS_ERR_HIP;
+        else link = VS_NODE_LINK_PEER;
         (void)hipGetLastError();
       }
     }
+    nd->link.push_back(link);
   }
   if (rc != VS_OK) {
     vs_node_destroy(nd);
@@ -89,9 +129,109 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
   return VS_OK;
 }
 
+static void vs_node_drop_rccl(vs_node *nd)
+{
+  for (size_t s = 0; s < nd->comm.size(); s++) {
+    if (nd->comm[s] && nd->rccl.CommDestroy) {
+      (void)hipSetDevice(nd->device[s]);
+      (void)nd->rccl.CommDestroy(nd->comm[s]);
+    }
+  }
+  nd->comm.clear();
+  if (!nd->recv.empty()) (void)hipSetDevice(nd->device[0]);
+  for (hipStream_t st : nd->recv)
+    if (st) (void)hipStreamDestroy(st);
+  nd->recv.clear();
+  if (nd->rccl.lib) dlclose(nd->rccl.lib);
+  memset(&nd->rccl, 0, sizeof(nd->rccl));
+}
+
+extern "C" int vs_node_set_transport(vs_node *nd, int transport)
+{
+  if (!nd || (transport != VS_NODE_TRANSPORT_PEER && transport != VS_NODE_TRANSPORT_RCCL)) return VS_ERR_ARG;
+  if (transport == nd->transport) return VS_OK;
+  if (transport == VS_NODE_TRANSPORT_PEER) {
+    vs_node_drop_rccl(nd);
+    nd->transport = transport;
+    for (size_t s = 0; s < nd->link.size(); s++)
+      if (nd->link[s] == VS_NODE_LINK_RCCL) nd->link[s] = VS_NODE_LINK_PEER;
+    return VS_OK;
+  }
+  /* RCCL puts one rank on one device: logical shards of one device cannot form a communicator */
+  const size_t S = nd->device.size();
+  for (size_t a = 0; a < S; a++)
+    for (size_t b = a + 1; b < S; b++)
+      if (nd->device[a] == nd->device[b]) return VS_ERR_UNSUPPORTED;
+  VsRccl &R = nd->rccl;
+  /* the RCCL that belongs to the HIP runtime this process runs on: the one next to libamdhip64
+   * (a process may hold a second ROCm, e.g. the copy bundled with PyTorch, and RCCL on the wrong HSA
+   * runtime finds no device), then whatever the loader finds by name */
+  {
+    Dl_info info;
+    char path[1024];
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+      const char *slash = strrchr(info.dli_fname, '/');
+      if (slash && (size_t)(slash - info.dli_fname) + 16 < sizeof(path)) {
+        const size_t dir = (size_t)(slash - info.dli_fname) + 1;
+        memcpy(path, info.dli_fname, dir);
+        strcpy(path + dir, "librccl.so.1");
+        R.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!R.lib) {
+          strcpy(path + dir, "librccl.so");
+          R.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        }
+      }
+    }
+  }
+  if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!R.lib) return VS_ERR_UNSUPPORTED;
+  R.CommInitAll = (int (*)(vs_nccl_comm *, int, const int *))dlsym(R.lib, "ncclCommInitAll");
+  R.CommDestroy = (int (*)(vs_nccl_comm))dlsym(R.lib, "ncclCommDestroy");
+  R.Send = (int (*)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclSend");
+  R.Recv = (int (*)(void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclRecv");
+  R.GroupStart = (int (*)(void))dlsym(R.lib, "ncclGroupStart");
+  R.GroupEnd = (int (*)(void))dlsym(R.lib, "ncclGroupEnd");
+  if (!R.CommInitAll || !R.CommDestroy || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
+    vs_node_drop_rccl(nd);
+    return VS_ERR_UNSUPPORTED;
+  }
+  nd->comm.assign(S, nullptr);
+  const int e = R.CommInitAll(nd->comm.data(), (int)S, nd->device.data());
+  if (e != 0) {
+    nd->last_rccl_error = e;
+    nd->comm.clear();
+    vs_node_drop_rccl(nd);
+    return VS_ERR_HIP;
+  }
+  /* the root receives every peer on a stream of its own: one per xGMI link */
+  hipError_t he = hipSetDevice(nd->device[0]);
+  for (size_t s = 0; s < S && he == hipSuccess; s++) {
+    hipStream_t st = nullptr;
+    he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    nd->recv.push_back(st);
+  }
+  if (he != hipSuccess) {
+    vs_node_drop_rccl(nd);
+    return VS_ERR_HIP;
+  }
+  nd->transport = transport;
+  for (size_t s = 1; s < S; s++) nd->link[s] = VS_NODE_LINK_RCCL;
+  return VS_OK;
+}
+
+extern "C" int vs_node_link(const vs_node *nd, int shard)
+{
+  if (!nd || shard < 0 || shard >= (int)nd->link.size()) return VS_ERR_ARG;
+  return nd->link[(size_t)shard];
+}
+
+extern "C" int vs_node_last_rccl_error(const vs_node *nd) { return nd ? nd->last_rccl_error : 0; }
+
 extern "C" void vs_node_destroy(vs_node *nd)
 {
   if (!nd) return;
+  vs_node_drop_rccl(nd);
   for (size_t s = 0; s < nd->ctx.size(); s++) {
     (void)hipSetDevice(nd->device[s]);
     if (s < nd->compute.size() && nd->compute[s]) (void)hipStreamDestroy(nd->compute[s]);
@@ -145,7 +285,7 @@ struct ShardJob {
   vs_node *nd;
   size_t s;
   const vs_lane *lanes;
-  size_t lo, hi, n_samples;
+  size_t lo, hi, n_samples, n_total;
   int16_t *root;      /* device pointer on device[0]: int16 [n_lanes][root_pitch] */
   size_t root_pitch;
   int flags;          /* VS_NODE_OVERLAP, VS_NODE_STAGE_ALL */
@@ -167,11 +307,14 @@ void shard_gather(ShardJob *j)
   }
   VsPool &P = ctx->pool;
   const size_t rows_all = j->hi - j->lo;
-  const size_t pitch = (j->n_samples + 7) & ~(size_t)7;
   /* the root's own shard is synthesised in place, in ONE launch: nothing travels, so there is
    * nothing to overlap, and a whole shard fills the chip where a chunk fills a quarter of it */
-  const bool in_place = (nd->device[s] == nd->device[0]) && !(j->flags & VS_NODE_STAGE_ALL);
+  const bool rccl = nd->transport == VS_NODE_TRANSPORT_RCCL;
+  const bool in_place = (nd->device[s] == nd->device[0]) && !((j->flags & VS_NODE_STAGE_ALL) && !rccl);
   const size_t chunk = in_place ? rows_all : std::min<size_t>(rows_all, VS_NODE_CHUNK);
+  /* an RCCL message is one contiguous range: chunks are synthesised at pitch n_samples and land in a
+   * root buffer of that pitch (checked by the caller) */
+  const size_t pitch = rccl ? j->n_samples : ((j->n_samples + 7) & ~(size_t)7);
   if (!in_place) {
     for (int k = 0; k < 2 && (k == 0 || rows_all > chunk); k++) {
       j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
@@ -205,7 +348,20 @@ void shard_gather(ShardJob *j)
       if (j->rc != VS_OK) break;
       e = hipEventRecord(nd->ev_done[k][s], nd->compute[s]);
     }
-    if (e == hipSuccess && (j->flags & VS_NODE_OVERLAP)) {
+    if (e == hipSuccess && rccl) {
+      /* the chunk leaves by ncclSend behind its kernel; the root's thread posts the matching receive */
+      e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
+      if (e == hipSuccess) {
+        const int ne = nd->rccl.Send(P.d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
+        if (ne != 0) {
+          nd->last_rccl_error = ne;
+          j->rc = VS_ERR_HIP;
+          break;
+        }
+        e = hipEventRecord(nd->ev_copied[k][s], nd->copy[s]);
+      }
+      used[k] = true;
+    } else if (e == hipSuccess && (j->flags & VS_NODE_OVERLAP)) {
       e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
       if (e == hipSuccess)
         e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P.d_out[k], pitch * 2, j->n_samples * 2, rows,
@@ -224,6 +380,42 @@ void shard_gather(ShardJob *j)
     if (e != hipSuccess) {
       ctx->last_hip_error = (int)e;
       j->rc = VS_ERR_HIP;
+    }
+  }
+  if (rccl && s == 0 && j->rc == VS_OK && nd->ctx.size() > 1) {
+    /* the root's side of the exchange: chunk k of every peer as one group, each receive on the
+     * stream of that peer's link, straight into the peer's rows of the root buffer */
+    const size_t S = nd->ctx.size();
+    size_t rounds = 0;
+    for (size_t p = 1; p < S; p++) {
+      size_t lo, hi;
+      shard_range(j->n_total, S, p, &lo, &hi);
+      rounds = std::max(rounds, (hi - lo + VS_NODE_CHUNK - 1) / VS_NODE_CHUNK);
+    }
+    for (size_t kk = 0; kk < rounds && j->rc == VS_OK; kk++) {
+      int ne = nd->rccl.GroupStart();
+      for (size_t p = 1; p < S && ne == 0; p++) {
+        size_t lo, hi;
+        shard_range(j->n_total, S, p, &lo, &hi);
+        const size_t r0 = lo + kk * VS_NODE_CHUNK;
+        if (r0 >= hi) continue;
+        const size_t rows = std::min<size_t>(VS_NODE_CHUNK, hi - r0);
+        ne = nd->rccl.Recv(j->root + r0 * j->root_pitch, rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, (int)p,
+                           nd->comm[0], nd->recv[p]);
+      }
+      const int ge = nd->rccl.GroupEnd();
+      if (ne == 0) ne = ge;
+      if (ne != 0) {
+        nd->last_rccl_error = ne;
+        j->rc = VS_ERR_HIP;
+      }
+    }
+    for (size_t p = 1; p < S; p++) {
+      const hipError_t re = hipStreamSynchronize(nd->recv[p]);
+      if (re != hipSuccess && j->rc == VS_OK) {
+        ctx->last_hip_error = (int)re;
+        j->rc = VS_ERR_HIP;
+      }
     }
   }
   hipError_t e = hipStreamSynchronize(nd->compute[s]);
@@ -247,6 +439,8 @@ extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_
                                     double *max_compute_ms)
 {
   if (!nd || !lanes || !root_dev || n_lanes == 0 || n_samples == 0 || root_pitch < n_samples) return VS_ERR_ARG;
+  /* RCCL messages are contiguous: the root buffer must be packed */
+  if (nd->transport == VS_NODE_TRANSPORT_RCCL && root_pitch != n_samples) return VS_ERR_UNSUPPORTED;
   const size_t S = nd->ctx.size();
   std::vector<ShardJob> jobs(S);
   std::vector<std::thread> th;
@@ -258,6 +452,7 @@ extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_
     j.lanes = lanes;
     shard_range(n_lanes, S, s, &j.lo, &j.hi);
     j.n_samples = n_samples;
+    j.n_total = n_lanes;
     j.root = root_dev;
     j.root_pitch = root_pitch;
     j.flags = flags;

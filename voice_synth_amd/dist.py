@@ -10,14 +10,7 @@ gloo in the CPU tests): point-to-point sends, one per peer link, no ring (SURVEY
 import torch
 import torch.distributed as dist
 
-
-def shard_range(n_lanes, rank, world):
-    """Contiguous lane block [lo, hi) of `rank`; blocks differ by at most one lane.  The same cut as
-    vs_node_shard_range() in csrc/vs_node.hip (tests/test_sharding_gloo.py holds them together)."""
-    base, rem = divmod(int(n_lanes), int(world))
-    lo = rank * base + min(rank, rem)
-    hi = lo + base + (1 if rank < rem else 0)
-    return lo, hi
+from .configs import shard_range  # noqa: F401  (the cut itself needs no torch)
 
 
 def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
