@@ -183,3 +183,33 @@ def test_oracle_against_the_compiled_reference_over_the_option_fuzz(draw, dur):
         assert np.array_equal(po.filter([lane], flow[None, :])[0], ref["pcm"]), (fa, va, seed)
         compared += 1
     assert compared > 100, compared
+
+
+@pytest.mark.parametrize("prog,argv", [
+    # flowgen_shimmer only notes WHERE a value stands and converts the last one: an early bad value is never seen
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.1", "-d", "0.5"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-d", "0.1"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-f", "200", "-g", "250"]),   # F0 against the Fg of the same line
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-g", "250", "-f", "250"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-l", "0.3"]),                 # 0.3f > 0.3
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-n", "20", "-l", "0.1", "-a", "1000"]),
+    # vowel converts every value where it stands
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-g", "0", "-g", "5"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-g", "5", "-g", "2"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "8", "-v", "a"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-n", "0"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-p", "nan"]),
+])
+def test_repeated_and_order_dependent_options_as_the_reference_takes_them(prog, argv):
+    with tempfile.TemporaryDirectory(prefix="vsfz") as d:
+        if prog == "vowel":
+            assert _run_ref("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5"], d, 5).returncode == 0
+        out = "g.wav" if prog == "flowgen_shimmer" else "o.wav"
+        if prog == "flowgen_shimmer" and os.path.exists(os.path.join(d, out)):
+            os.remove(os.path.join(d, out))
+        ref = _run_ref(prog, argv, d, 5)
+        ref_ran = os.path.exists(os.path.join(d, out)) and b"usage:" not in ref.stdout
+    rc, cmd = (vs.parse_flowgen if prog == "flowgen_shimmer" else vs.parse_vowel)(argv)
+    assert (rc == 0) == ref_ran, (argv, rc, ref.stdout[:60])
+    if rc == 0 and prog == "flowgen_shimmer":
+        assert cmd.dur == np.float32(argv[argv.index("-d", argv.index("-d") + 1) + 1] if argv.count("-d") > 1 else 0.5)

@@ -145,166 +145,194 @@ int vs_lane_validate(const vs_lane *lane)
 }
 
 /* ------------------------------------------------------------------------------------------
- * flowgen_shimmer command line: option loop fg:128-219, initialization() fg:463-546
+ * The two command lines.  Both programs of the reference take "-x value" pairs, look at the first
+ * letter behind the dash only, in either case (flowgen_shimmer.c:130-218, vowel_new.c:118-190), and
+ * answer anything else with usage().  Here each program is a TABLE of its options -- letter, how
+ * the text becomes a number, the range the reference accepts, where the value goes -- and one
+ * scanner walks the argument vector for both.  What differs between the two programs is WHEN a value
+ * is looked at, and the tables say so:
+ *   flowgen_shimmer only notes where each value stands while it scans (a later -d overrides an
+ *     earlier one unseen) and converts afterwards, in the fixed order of its initialization()
+ *     (fg:470-546) -- which is the order of vs_flowgen_opts[], and matters: F0 is held against the
+ *     Fg of the same command line, the DC flow is a fraction of its amplitude;
+ *   vowel converts and checks every value where it stands (vw:123-187): "-g 0 -g 5" is refused.
+ * tests/test_parser_vs_reference.py holds both against the compiled reference on random lines.
  * ---------------------------------------------------------------------------------------- */
+enum { VS_CV_NONE, VS_CV_FLOAT, VS_CV_PERCENT, VS_CV_INT, VS_CV_LONG, VS_CV_VOWEL };
+enum {
+  VS_TO_NOTHING, VS_TO_DUR, VS_TO_JITTER, VS_TO_K, VS_TO_CQ, VS_TO_FG, VS_TO_F0, VS_TO_NOISE_DB, VS_TO_AMP,
+  VS_TO_DC_FRACTION, VS_TO_KVAR, VS_TO_FS, VS_TO_SHIMMER_PERCENT, VS_TO_PRE, VS_TO_GAIN, VS_TO_SNR_DB, VS_TO_VOWEL
+};
+#define VS_OPT_BELOW_FG 0x1    /* upper bound: strictly below the Fg of the same command line (fg:504) */
+#define VS_OPT_NOT_22050 0x2   /* every rate but an explicit 22050 (fg:537) */
+#define VS_OPT_DC_QUARTER 0x4  /* seeing the option sets the DC flow to .25 at once (fg:182) */
+#define VS_OPT_REJECTS 0x8     /* the reference tests "outside -> usage()" (a NaN passes) instead of
+                                  "inside -> accept" (a NaN fails): vowel's -p, -g, -n */
+#define VS_OPT_LO_OPEN 0x10    /* the lower bound itself is refused (vowel -n: snr <= 0, vw:142) */
+typedef struct vs_opt {
+  char letter;         /* lower case */
+  unsigned char conv;  /* VS_CV_* */
+  unsigned char to;    /* VS_TO_* */
+  unsigned char how;   /* VS_OPT_* */
+  double lo, hi;       /* the accepted range, both ends included unless `how` says otherwise */
+  uint32_t lane_flag;  /* VS_FLAG_* raised when the option is given */
+} vs_opt;
+
+#define VS_NO_LIMIT 1e300
+static const vs_opt vs_flowgen_opts[] = {
+    /* in the order initialization() converts them, fg:470-546 */
+    {'d', VS_CV_FLOAT, VS_TO_DUR, 0, 0.5, VS_NO_LIMIT, 0},                           /* fg:470-474 */
+    {'j', VS_CV_PERCENT, VS_TO_JITTER, 0, 0.0, 10.0, VS_FLAG_JITTER},                /* fg:476-480 */
+    {'k', VS_CV_FLOAT, VS_TO_K, 0, 0.50, VS_NO_LIMIT, 0},                            /* fg:482-486 */
+    {'c', VS_CV_FLOAT, VS_TO_CQ, 0, 0.0, 1.0, 0},                                    /* fg:488-492 */
+    {'g', VS_CV_FLOAT, VS_TO_FG, 0, 50, VS_NO_LIMIT, 0},                             /* fg:494-498 */
+    {'f', VS_CV_FLOAT, VS_TO_F0, VS_OPT_BELOW_FG, 50, 0, 0},                         /* fg:500-506 */
+    {'n', VS_CV_FLOAT, VS_TO_NOISE_DB, VS_OPT_DC_QUARTER, 0.0, 50, VS_FLAG_NOISE},   /* fg:508-514 */
+    {'a', VS_CV_INT, VS_TO_AMP, 0, 0, 32766, 0},                                     /* fg:516-520 */
+    {'l', VS_CV_FLOAT, VS_TO_DC_FRACTION, 0, 0, 0.3, 0},                             /* fg:522-526 */
+    {'z', VS_CV_FLOAT, VS_TO_KVAR, 0, 0, 1, 0},                                      /* fg:528-532 */
+    {'r', VS_CV_LONG, VS_TO_FS, VS_OPT_NOT_22050, 0, 0, 0},                          /* fg:534-540 */
+    {'s', VS_CV_FLOAT, VS_TO_SHIMMER_PERCENT, 0, 0, 100, VS_FLAG_SHIMMER},           /* fg:542-546 */
+    {'o', VS_CV_NONE, VS_TO_NOTHING, 0, 0, 0, 0},                                    /* the file name */
+};
+static const vs_opt vs_vowel_opts[] = {
+    {'p', VS_CV_FLOAT, VS_TO_PRE, VS_OPT_REJECTS, 0.0, 1.0, 0},                          /* vw:125-128 */
+    {'g', VS_CV_FLOAT, VS_TO_GAIN, VS_OPT_REJECTS, 1, VS_NO_LIMIT, 0},                   /* vw:130-133 */
+    {'n', VS_CV_FLOAT, VS_TO_SNR_DB, VS_OPT_REJECTS | VS_OPT_LO_OPEN, 0, VS_NO_LIMIT, 0}, /* vw:139-144 */
+    {'v', VS_CV_VOWEL, VS_TO_VOWEL, 0, 0, 0, 0},                                         /* vw:153-178 */
+    {'i', VS_CV_NONE, VS_TO_NOTHING, 0, 0, 0, 0},
+    {'o', VS_CV_NONE, VS_TO_NOTHING, 0, 0, 0, 0},
+};
+#define VS_COUNT(t) ((int)(sizeof(t) / sizeof((t)[0])))
+
+/* everything a value can be stored into */
+typedef struct vs_opt_sink {
+  vs_lane *lane;
+  float *dur, *pre, *gain, *snr;
+  int32_t *vowel;
+} vs_opt_sink;
+
+/* One value through its rule: conversion with the reference's own types (the reference converts
+ * into a `float f`, so ranges are tested on the ROUNDED value: "-l 0.3" is 0.3f > 0.3 and refused),
+ * range, store.  VS_OK or VS_USAGE. */
+static int vs_opt_apply(const vs_opt *o, const char *text, const vs_opt_sink *k)
+{
+  vs_lane *par = k->lane;
+  if (o->conv == VS_CV_NONE) return VS_OK;
+  if (o->conv == VS_CV_VOWEL) { /* vw:155-171: the first character, one of these */
+    if (text[0] == '\0' || !strchr("iauIAU1234567", text[0])) return VS_USAGE;
+    *k->vowel = (int)text[0];
+    return VS_OK;
+  }
+  if (o->conv == VS_CV_INT) {
+    const int v = atoi(text);
+    if (!(v >= (int)o->lo && v <= (int)o->hi)) return VS_USAGE;
+    par->amp = v;
+    return VS_OK;
+  }
+  if (o->conv == VS_CV_LONG) {
+    const long v = atol(text);
+    if ((o->how & VS_OPT_NOT_22050) && v == 22050L) return VS_USAGE;
+    par->fs = (int32_t)v;
+    return VS_OK;
+  }
+  const float f = (o->conv == VS_CV_PERCENT) ? (float)(atof(text) / 100.0) : (float)atof(text);
+  int inside;
+  if (o->how & VS_OPT_REJECTS) {
+    const int outside = ((o->how & VS_OPT_LO_OPEN) ? (f <= o->lo) : (f < o->lo)) || (f > o->hi);
+    inside = !outside;
+  } else {
+    inside = (f >= o->lo) && ((o->how & VS_OPT_BELOW_FG) ? (f < par->Fg) : (f <= o->hi));
+  }
+  if (!inside) return VS_USAGE;
+  switch (o->to) {
+    case VS_TO_DUR: *k->dur = f; break;
+    case VS_TO_JITTER: par->jitter = f; break;
+    case VS_TO_K: par->K = f; break;
+    case VS_TO_CQ: par->cq = f; break;
+    case VS_TO_FG: par->Fg = f; break;
+    case VS_TO_F0: par->F0 = f; break;
+    case VS_TO_NOISE_DB: par->noise = pow(10, f / 10); break;      /* fg:511 */
+    case VS_TO_DC_FRACTION: par->DC = f * par->amp; break;         /* fg:524: of the amplitude set above */
+    case VS_TO_KVAR: par->Kvar = f; break;
+    case VS_TO_SHIMMER_PERCENT: par->shimmer = f / 100; break;     /* fg:544 */
+    case VS_TO_PRE: *k->pre = f; break;
+    case VS_TO_GAIN: *k->gain = f; break;
+    case VS_TO_SNR_DB: *k->snr = pow(10, f / 10); break;           /* vw:143 */
+    default: break;
+  }
+  par->flags |= o->lane_flag;
+  return VS_OK;
+}
+
+/* The scanner: "-x value" pairs from argv[1] on, first letter behind the dash, either case.
+ * at[r] receives the argv index of the LAST value given for rule r (-1: not given).  on_sight:
+ * every value goes through its rule where it stands (vowel); otherwise only the parse-time side
+ * effects happen here (flowgen's -n).  A trailing word is tolerated if it starts with 'i', as in
+ * both programs (fg:219, vw:191).  VS_OK or VS_USAGE. */
+static int vs_opt_scan(int argc, char **argv, const vs_opt *tab, int n_opts, int on_sight, const vs_opt_sink *k, int *at)
+{
+  for (int r = 0; r < n_opts; r++) at[r] = -1;
+  if (argc < 2) return VS_USAGE;
+  int i = 1;
+  while (i < argc && argv[i][0] == '-') {
+    if (i + 1 >= argc) return VS_USAGE; /* an option without its value */
+    char c = argv[i][1];
+    if (c >= 'A' && c <= 'Z') c = (char)(c - 'A' + 'a');
+    int r = 0;
+    while (r < n_opts && tab[r].letter != c) r++;
+    if (r == n_opts) return VS_USAGE;
+    at[r] = i + 1;
+    if (tab[r].how & VS_OPT_DC_QUARTER) k->lane->DC = .25;
+    if (on_sight && vs_opt_apply(&tab[r], argv[i + 1], k) != VS_OK) return VS_USAGE;
+    i += 2;
+  }
+  if (i != argc && argv[i][0] != 'i') return VS_USAGE;
+  return VS_OK;
+}
+
+static int vs_opt_index(const vs_opt *tab, int n_opts, char letter)
+{
+  for (int r = 0; r < n_opts; r++)
+    if (tab[r].letter == letter) return r;
+  return -1;
+}
+
 int vs_flowgen_parse(int argc, char **argv, vs_flowgen_cmd *cmd)
 {
-  /* struct ARG, fg:90-102 */
-  int a_wav = -1, a_dur = -1, a_jitter = -1, a_cq = -1, a_K = -1, a_Fg = -1, a_F0 = -1,
-      a_DC = -1, a_noise = -1, a_fs = -1, a_amp = -1, a_Kvar = -1, a_Shimmer = -1;
-  int i, j;
-  float f;
-  long l;
   if (!cmd || !argv) return VS_ERR_ARG;
   vs_lane *par = &cmd->lane;
   vs_lane_defaults(par);
   cmd->dur = 1.0f;
   cmd->wav_arg = -1;
-
-  if (argc < 2) return VS_USAGE; /* fg:128 */
-
-  for (i = 1; i < argc && *argv[i] == '-'; i++) { /* fg:130 */
-    j = i + 1;
-    if (argc <= j) return VS_USAGE; /* fg:135 */
-    switch (argv[i++][1]) {
-      case 'o': case 'O': a_wav = i; break;
-      case 'g': case 'G': a_Fg = i; break;
-      case 'f': case 'F': a_F0 = i; break;
-      case 'd': case 'D': a_dur = i; break;
-      case 'c': case 'C': a_cq = i; break;
-      case 'j': case 'J': a_jitter = i; break;
-      case 'k': case 'K': a_K = i; break;
-      case 'n': case 'N':
-        par->DC = .25; /* fg:182: -n sets the DC flow at parse time */
-        a_noise = i;
-        break;
-      case 'r': case 'R': a_fs = i; break;
-      case 'a': case 'A': a_amp = i; break;
-      case 'l': case 'L': a_DC = i; break;
-      case 'z': case 'Z': a_Kvar = i; break;
-      case 's': case 'S': a_Shimmer = i; break;
-      default: return VS_USAGE; /* fg:212 */
-    }
-  }
-  if ((i != argc && *argv[i] != 'i') || a_wav == -1) return VS_USAGE; /* fg:219 */
-
-  /* initialization(), same order as fg:470-546 */
-  if (a_dur != -1) {
-    f = atof(argv[a_dur]);
-    if (f >= 0.5) cmd->dur = f;
-    else return VS_USAGE;
-  }
-  if (a_jitter != -1) {
-    f = atof(argv[a_jitter]) / 100.0;
-    if (f >= 0.0 && f <= 10.0) par->jitter = f;
-    else return VS_USAGE;
-    par->flags |= VS_FLAG_JITTER;
-  }
-  if (a_K != -1) {
-    f = atof(argv[a_K]);
-    if (f >= 0.50) par->K = f;
-    else return VS_USAGE;
-  }
-  if (a_cq != -1) {
-    f = atof(argv[a_cq]);
-    if (f >= 0.0 && f <= 1.0) par->cq = f;
-    else return VS_USAGE;
-  }
-  if (a_Fg != -1) {
-    f = atof(argv[a_Fg]);
-    if (f >= 50) par->Fg = f;
-    else return VS_USAGE;
-  }
-  if (a_F0 != -1) {
-    f = atof(argv[a_F0]);
-    if ((f >= 50) && (f < par->Fg)) par->F0 = f;
-    else return VS_USAGE;
-  }
-  if (a_noise != -1) {
-    f = atof(argv[a_noise]);
-    if (f >= 0.0 && f <= 50) {
-      par->noise = pow(10, f / 10);
-    } else return VS_USAGE;
-    par->flags |= VS_FLAG_NOISE;
-  }
-  if (a_amp != -1) {
-    int iv = atoi(argv[a_amp]);
-    if (iv >= 0 && iv < 32767) par->amp = iv;
-    else return VS_USAGE;
-  }
-  if (a_DC != -1) {
-    f = atof(argv[a_DC]);
-    if (f >= 0 && f <= 0.3) par->DC = f * par->amp;
-    else return VS_USAGE;
-  }
-  if (a_Kvar != -1) {
-    f = atof(argv[a_Kvar]);
-    if (f >= 0 && f <= 1) par->Kvar = f;
-    else return VS_USAGE;
-  }
-  if (a_fs != -1) {
-    l = atol(argv[a_fs]);
-    /* fg:537 accepts everything except 22050 */
-    if ((l == 44100L) || (l != 22050L) || (l == 11025L)) par->fs = (int32_t)l;
-    else return VS_USAGE;
-  }
-  if (a_Shimmer != -1) {
-    f = atof(argv[a_Shimmer]);
-    if (f >= 0 && f <= 100) par->shimmer = f / 100;
-    else return VS_USAGE;
-    par->flags |= VS_FLAG_SHIMMER;
-  }
-  cmd->wav_arg = a_wav;
+  const vs_opt_sink sink = {par, &cmd->dur, NULL, NULL, NULL, NULL};
+  int at[VS_COUNT(vs_flowgen_opts)];
+  if (vs_opt_scan(argc, argv, vs_flowgen_opts, VS_COUNT(vs_flowgen_opts), 0, &sink, at) != VS_OK) return VS_USAGE;
+  const int o = vs_opt_index(vs_flowgen_opts, VS_COUNT(vs_flowgen_opts), 'o');
+  if (at[o] == -1) return VS_USAGE; /* fg:219: no output file */
+  for (int r = 0; r < VS_COUNT(vs_flowgen_opts); r++)
+    if (at[r] != -1 && vs_opt_apply(&vs_flowgen_opts[r], argv[at[r]], &sink) != VS_OK) return VS_USAGE;
+  cmd->wav_arg = at[o];
   return VS_OK;
 }
 
-/* ------------------------------------------------------------------------------------------
- * vowel command line: vowel_new.c:116-192
- * ---------------------------------------------------------------------------------------- */
 int vs_vowel_parse(int argc, char **argv, vs_vowel_cmd *cmd)
 {
-  int i, j;
   if (!cmd || !argv) return VS_ERR_ARG;
   cmd->gain = 10.0f;
   cmd->pre_emphasis = 1.0f;
   cmd->snr = 0.0f;
   cmd->vowel = 0;
   cmd->input_arg = cmd->output_arg = cmd->noise_arg = -1;
-  int algorithm_arg = -1;
-
-  if (argc < 2) return VS_USAGE; /* vw:116 */
-  for (i = 1; i < argc && *argv[i] == '-'; i++) {
-    if (argc <= i + 1) return VS_USAGE; /* vw:121 */
-    switch (argv[i++][1]) {
-      case 'p': case 'P':
-        cmd->pre_emphasis = atof(argv[i]);
-        if (cmd->pre_emphasis < 0.0 || cmd->pre_emphasis > 1.0) return VS_USAGE;
-        break;
-      case 'g': case 'G':
-        cmd->gain = atof(argv[i]);
-        if (cmd->gain < 1) return VS_USAGE;
-        break;
-      case 'i': case 'I': cmd->input_arg = i; break;
-      case 'n': case 'N':
-        cmd->noise_arg = i;
-        cmd->snr = atof(argv[i]);
-        if (cmd->snr <= 0) return VS_USAGE;
-        else cmd->snr = pow(10, cmd->snr / 10);
-        break;
-      case 'o': case 'O': cmd->output_arg = i; break;
-      case 'v': case 'V':
-        algorithm_arg = i;
-        j = (int)argv[i][0];
-        if (j == 'i' || j == 'a' || j == 'u' || j == 'I' || j == 'A' || j == 'U' || j == '1' ||
-            j == '2' || j == '3' || j == '4' || j == '5' || j == '6' || j == '7') {
-          cmd->vowel = j;
-        } else return VS_USAGE;
-        break;
-      default: return VS_USAGE;
-    }
-  }
-  if ((i != argc && *argv[i] != 'i') || cmd->input_arg == -1 || algorithm_arg == -1)
-    return VS_USAGE; /* vw:191 */
+  vs_lane unused; /* no vowel option touches a lane; the sink wants one for the rules that do */
+  memset(&unused, 0, sizeof(unused));
+  const vs_opt_sink sink = {&unused, NULL, &cmd->pre_emphasis, &cmd->gain, &cmd->snr, &cmd->vowel};
+  int at[VS_COUNT(vs_vowel_opts)];
+  if (vs_opt_scan(argc, argv, vs_vowel_opts, VS_COUNT(vs_vowel_opts), 1, &sink, at) != VS_OK) return VS_USAGE;
+  cmd->input_arg = at[vs_opt_index(vs_vowel_opts, VS_COUNT(vs_vowel_opts), 'i')];
+  cmd->output_arg = at[vs_opt_index(vs_vowel_opts, VS_COUNT(vs_vowel_opts), 'o')];
+  cmd->noise_arg = at[vs_opt_index(vs_vowel_opts, VS_COUNT(vs_vowel_opts), 'n')];
+  if (cmd->input_arg == -1 || at[vs_opt_index(vs_vowel_opts, VS_COUNT(vs_vowel_opts), 'v')] == -1) return VS_USAGE; /* vw:191 */
   return VS_OK;
 }
 
