@@ -77,6 +77,15 @@ def test_vs_batch_manifest(tmp_path):
         assert sha(raw[44:]) == CASES[n]["sha256_pcm"], n
 
 
+def test_vs_batch_refuses_two_lines_with_one_output(tmp_path):
+    c = CASES["cfg3_lane0"]
+    line = "seed=%d -o same.wav %s | %s" % (c["seed"], " ".join(c["flowgen_args"]), " ".join(c["vowel_args"]))
+    (tmp_path / "m.txt").write_text(line + "\n" + line.replace("seed=%d" % c["seed"], "seed=99") + "\n")
+    r = subprocess.run([os.path.join(BIN, "vs_batch"), "m.txt"], cwd=tmp_path, capture_output=True)
+    assert r.returncode == 1 and b"more than one line" in r.stderr
+    assert not os.path.exists(tmp_path / "same.wav")
+
+
 def test_vs_batch_sharded_over_logical_devices(tmp_path):
     """vs_batch --gpus 4 with VS_DEVICES=0,0,0,0: four logical shards of the one device, each a
     contiguous block of the manifest; the files must not depend on the sharding"""

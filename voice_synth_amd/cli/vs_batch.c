@@ -62,6 +62,11 @@ typedef struct {
   volatile int failed;
 } sink;
 
+static int cmp_job_path(const void *a, const void *b)
+{
+  return strcmp((*(const job *const *)a)->path, (*(const job *const *)b)->path);
+}
+
 /* vs_rows_cb: called from the delivery threads, concurrently for different blocks (distinct
  * files, so no locking) */
 static int write_rows(void *user, size_t row0, size_t rows, const int16_t *pcm)
@@ -79,7 +84,11 @@ static int write_rows(void *user, size_t row0, size_t rows, const int16_t *pcm)
       sk->failed = 1;
       return 1;
     }
-    fclose(f);
+    if (fclose(f) != 0) { /* a write error may only surface here (a full disk): the file is not done */
+      fprintf(stderr, "vs_batch: cannot write %s\n", j->path);
+      sk->failed = 1;
+      return 1;
+    }
     j->done = 1;
   }
   return 0;
@@ -170,6 +179,20 @@ int main(int argc, char **argv)
     fprintf(stderr, "vs_batch: out of memory\n");
     return 1;
   }
+  /* two lines naming one output file would be written by two delivery threads at once */
+  {
+    const job **by_path = (const job **)malloc((n_jobs ? n_jobs : 1) * sizeof(job *));
+    if (!by_path) return 1;
+    for (size_t k = 0; k < n_jobs; k++) by_path[k] = &jobs[k];
+    qsort(by_path, n_jobs, sizeof(job *), cmp_job_path);
+    for (size_t k = 1; k < n_jobs; k++) {
+      if (strcmp(by_path[k - 1]->path, by_path[k]->path) == 0) {
+        fprintf(stderr, "vs_batch: %s is the output of more than one line\n", by_path[k]->path);
+        return 1;
+      }
+    }
+    free(by_path);
+  }
   if (n_jobs == 0) {
     fprintf(stderr, "vs_batch: empty manifest\n");
     return 1;
@@ -223,8 +246,19 @@ int main(int argc, char **argv)
     int rc = node ? vs_node_synth_rows(node, lanes, m, (size_t)ns, write_rows, &sk)
                   : vs_synth_rows(ctx, lanes, m, (size_t)ns, write_rows, &sk);
     if (rc != VS_OK || sk.failed) {
-      if (!sk.failed)
-        fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d)\n", vs_strerror(rc), ctx ? vs_ctx_last_hip_error(ctx) : 0);
+      if (!sk.failed) {
+        /* with --gpus the HIP error lives in the failing shard's context */
+        int hip = ctx ? vs_ctx_last_hip_error(ctx) : 0, shard = -1;
+        for (int d = 0; node && d < gpus && hip == 0; d++) {
+          vs_ctx *c = NULL;
+          if (vs_node_ctx(node, d, &c) == VS_OK && vs_ctx_last_hip_error(c) != 0) {
+            hip = vs_ctx_last_hip_error(c);
+            shard = d;
+          }
+        }
+        if (shard >= 0) fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d on shard %d)\n", vs_strerror(rc), hip, shard);
+        else fprintf(stderr, "vs_batch: synthesis failed: %s (hip %d)\n", vs_strerror(rc), hip);
+      }
       return 1;
     }
     for (size_t q = 0; q < m; q++) {

@@ -55,6 +55,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   ctx->device = device;
   ctx->arith = VS_ARITH_EXACT;
   ctx->stream = nullptr;
+  ctx->upload = nullptr;
   ctx->last_hip_error = 0;
   snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
   ctx->cu_count = prop.multiProcessorCount;
@@ -623,16 +624,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       p->owns_flow = 1;
     }
   }
+  /* the records go up on the context's stream -- or, inside a chunk pipeline, on its upload stream, so
+   * that the wait below is for THESE copies and not for the previous chunk's kernel; the launch that
+   * uses them is enqueued after this function has returned */
+  hipStream_t up = ctx->upload ? ctx->upload : ctx->stream;
   if (e == hipSuccess && wide)
-    e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), ctx->stream);
+    e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, up);
+  if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), up);
   if (e == hipSuccess)
-    e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice,
-                       ctx->stream);
+    e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
   if (e == hipSuccess && !costab.empty())
-    e = hipMemcpyAsync(p->d_costab, costab.data(), costab.size() * sizeof(double),
-                       hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = hipMemcpyAsync(p->d_costab, costab.data(), costab.size() * sizeof(double), hipMemcpyHostToDevice, up);
+  if (e == hipSuccess) e = hipStreamSynchronize(up);
   if (e != hipSuccess) {
     ctx->last_hip_error = (int)e;
     if (p->d_lanes) (void)hipFree(p->d_lanes);

@@ -18,10 +18,11 @@
  *                    callbacks are in flight at once; a caller that passes PINNED memory
  *                    (vs_host_alloc) gets the DMA straight into it, no staging, no memcpy.
  *
- * All device and pinned buffers belong to the context and are reused by later calls
- * (vs_ctx_trim releases them); nothing here calls hipMalloc or hipHostMalloc per call once the
- * buffers have reached their size, and hipFree (which waits for the device) is never called
- * while a pipeline runs.
+ * The PCM buffers and the pinned staging buffers belong to the context and are reused by later
+ * calls (vs_ctx_trim releases them): once they have reached their size no call allocates them
+ * again, and hipFree of them (which waits for the device) never happens while a pipeline runs.
+ * What IS allocated per chunk are the plan's own small records (lane records, cos rows, error
+ * word: vs_plan_create_impl), uploaded on a stream of their own beside the running kernel.
  */
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -64,10 +65,16 @@ int vs_pool_streams(vs_ctx *ctx, size_t row_bytes)
   size_t want = VS_STAGING_BYTES;
   if (row_bytes > want) want = (row_bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
   if (P.streams_ready && P.staging_bytes >= want) return VS_OK;
+  /* Anything below may fail half way (VS_HIP returns): until ALL of it has succeeded the pool says
+   * "not ready, no staging", so that the next call starts over -- frees whatever is there and
+   * allocates afresh -- instead of trusting a staging pointer that a failed call left NULL. */
+  const size_t had = P.staging_bytes;
+  P.streams_ready = 0;
+  P.staging_bytes = 0;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
     if (!P.copy_stream[t]) VS_HIP(ctx, hipStreamCreateWithFlags(&P.copy_stream[t], hipStreamNonBlocking));
-    if (P.staging[t] && P.staging_bytes < want) { /* only between pipelines */
+    if (P.staging[t] && had < want) { /* only between pipelines */
       VS_HIP(ctx, hipHostFree(P.staging[t]));
       P.staging[t] = nullptr;
     }
@@ -75,6 +82,7 @@ int vs_pool_streams(vs_ctx *ctx, size_t row_bytes)
   }
   P.staging_bytes = want;
   if (!P.compute_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&P.compute_stream, hipStreamNonBlocking));
+  if (!P.upload_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&P.upload_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++)
     if (!P.done[k]) VS_HIP(ctx, hipEventCreateWithFlags(&P.done[k], hipEventDisableTiming));
   P.streams_ready = 1;
@@ -97,6 +105,7 @@ void vs_pool_release(vs_ctx *ctx)
     if (P.copy_stream[t]) (void)hipStreamDestroy(P.copy_stream[t]);
   }
   if (P.compute_stream) (void)hipStreamDestroy(P.compute_stream);
+  if (P.upload_stream) (void)hipStreamDestroy(P.upload_stream);
   memset(&P, 0, sizeof(P));
 }
 
@@ -252,13 +261,16 @@ static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   /* the caller's stream if there is one (its work is ordered before ours), else the context's own */
   hipStream_t cs = ctx->stream ? ctx->stream : P.compute_stream;
   hipStream_t saved = ctx->stream;
-  ctx->stream = cs; /* vs_plan_create / vs_plan_launch issue on the context's stream */
+  ctx->stream = cs; /* vs_plan_launch issues on the context's stream */
+  ctx->upload = P.upload_stream; /* vs_plan_create_impl: the next chunk's records go up beside this chunk's kernel */
   std::vector<vs_plan *> plans;
   int k = 0;
   for (size_t row0 = 0; row0 < n_lanes && pipe.rc.load() == VS_OK; row0 += chunk, k ^= 1) {
     const size_t rows = std::min(chunk, n_lanes - row0);
     vs_plan *plan = nullptr;
-    rc = vs_plan_create_impl(ctx, lanes + row0, rows, n_samples, VS_PLAN_POOL_SCRATCH, &plan); /* host work, overlaps the device */
+    /* host work (expansion, sort, cos rows), three small hipMalloc for the plan's own records, the
+     * upload on its own stream: all of it while the previous chunk's kernel runs */
+    rc = vs_plan_create_impl(ctx, lanes + row0, rows, n_samples, VS_PLAN_POOL_SCRATCH, &plan);
     if (rc != VS_OK) break;
     plans.push_back(plan);
     {
@@ -306,6 +318,7 @@ static int vs_synth_rows_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes,
   }
   for (vs_plan *pl : plans) vs_plan_destroy(pl);
   ctx->stream = saved;
+  ctx->upload = nullptr;
   return rc;
 }
 

@@ -29,6 +29,7 @@ struct VsPool {
   size_t staging_bytes;
   hipStream_t copy_stream[VS_DELIVERY_THREADS];
   hipStream_t compute_stream; /* compute chunks of vs_synth_rows when the caller set no stream */
+  hipStream_t upload_stream;  /* lane records + cos rows of the NEXT chunk's plan, while this chunk's kernel runs */
   hipEvent_t done[2];       /* kernel of the chunk in d_out[k] has finished */
   int streams_ready;
 };
@@ -37,6 +38,7 @@ struct vs_ctx {
   int device;
   int arith;
   hipStream_t stream;
+  hipStream_t upload;   /* when set (the chunk pipelines): plan records go up on this stream instead of `stream` */
   int last_hip_error;
   char name[128];
   int cu_count;
