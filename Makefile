@@ -32,6 +32,10 @@ $(CSRC)/vs_host.o: $(CSRC)/vs_host.c $(CSRC)/vs_tables.h include/voice_synth.h
 $(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
+# the one-wave kernel once more with 16 utterances per wavefront: periods beyond the 64-column ring
+$(CSRC)/vs_kernels_narrow.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+	$(HIPCC) $(HIPFLAGS) -DVS_GROUP_LANES=16 -c -o $@ $<
+
 $(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
@@ -41,7 +45,7 @@ $(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.hip $(CSRC)/vs_device.h $(CSRC)/vs_in
 $(CSRC)/vs_node.o: $(CSRC)/vs_node.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
+$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
@@ -66,11 +70,11 @@ clean:
 diag: $(LIBDIR)/libvoicesynth_diag.so
 $(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
-$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
+$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 # A/B variants of the library for same-box comparisons (tools/gpu_ab.sh):
 #   make variant NAME=sleep2 DEFS="-DVS_POLL_SLEEP=2"   ->  lib/libvoicesynth_sleep2.so   (select with VS_LIB)
-variant: $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
+variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels.hip
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread -ldl

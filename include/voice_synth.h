@@ -227,7 +227,9 @@ int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_c
  * 319, 328 call cos() per sample; T2 = ceil(.5*cq*P) is fixed per utterance), and uploads the
  * lane records.  The lanes array may be freed afterwards.
  * Limits (VS_ERR_UNSUPPORTED beyond them): n_lanes < 2^31 - 64, n_samples < 2^31 - 256, periods
- * whose ring does not fit a compute unit's LDS (fs/F0 above ~1000).  An utterance's draw stream is
+ * whose ring does not fit a compute unit's LDS: fs/F0 up to ~930 (with jitter; ~1120 without) runs
+ * on the kernels with 64 utterances per wavefront, up to ~3800 (~4500) on the narrow build of the
+ * one-wave kernel (16 utterances per wavefront, slow: vs_plan_kernel_name says which).  An utterance's draw stream is
  * indexed with 32 bits: about one draw per sample, so the sample limit keeps it in range for every
  * setting short of rejection loops that retry thousands of times per cycle. */
 int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,

@@ -83,6 +83,11 @@ def main():
     add("carry_t4_22k", ["-d", "0.5", "-a", "32000", "-s", "3", "-n", "10", "-l", "0", "-z", "0.3"],
         ["-v", "3", "-g", "2", "-p", "0.5"], 1, keep=False)
 
+    # --- periods beyond the engine's 64-column ring (the narrow build of the one-wave kernel): rates the
+    #     reference accepts (fg:535-540); without glottal noise, where its w[500] buffer is not in play ---
+    add("long_48k_f50_j5", ["-r", "48000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5"], ["-v", "a"], 31, keep=False)
+    add("long_96k_f60", ["-r", "96000", "-d", "0.5", "-f", "60", "-g", "70", "-s", "4"], ["-v", "2", "-g", "2"], 32, keep=False)
+
     manifest = []
     arrays = {}
     for name, fa, va, seed, keep in cases:

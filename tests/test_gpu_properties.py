@@ -104,9 +104,13 @@ def test_odd_sample_counts_and_pitches(engine):
         assert np.array_equal(got, want), n
 
 
-def test_longest_supported_period_and_beyond(engine):
-    """fs/F0 near the LDS limit of the ring (one workgroup per CU), where the reference itself
-    overflows its w[500] buffer; and just beyond it -> VS_ERR_UNSUPPORTED, not a wrong answer."""
+def test_longest_period_of_the_wide_ring_and_beyond(engine):
+    """fs/F0 near the LDS limit of the 64-column ring (one workgroup per CU), where the reference itself
+    overflows its w[500] buffer; beyond it the narrow build of the one-wave kernel takes over (16
+    utterances per wavefront, four times the slots): slow, but the samples the loops define -- 48 kHz and
+    96 kHz are rates the reference accepts (flowgen_shimmer.c:535-540) and its buffer grows with the
+    period (fg:569).  Beyond THAT (a period of more than ~4500 samples): VS_ERR_UNSUPPORTED, not a wrong
+    answer."""
     fa = ["-r", "44100", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5", "-s", "10", "-n", "15"]
     lanes = []
     for seed in range(70):
@@ -115,7 +119,18 @@ def test_longest_supported_period_and_beyond(engine):
     n = vs.num_samples(44100, dur)
     got = engine.synth(lanes, n)
     assert np.array_equal(got, po.synth(lanes, n))
-    lane, dur = vs.lane_from_cli(["-r", "48000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5"], ["-v", "a"], 1)
+    for fa, nl in ((["-r", "48000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5"], 40),
+                   (["-r", "48000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5", "-s", "10", "-n", "15"], 21),
+                   (["-r", "96000", "-d", "0.5", "-f", "60", "-g", "70"], 5),
+                   (["-r", "96000", "-d", "0.5", "-f", "50", "-g", "52", "-j", "3", "-s", "4", "-n", "30", "-l", "0.1"], 33)):
+        lanes = [vs.lane_from_cli(fa, ["-v", "aiu1234567"[seed % 10], "-g", "2"], 300 + seed)[0] for seed in range(nl)]
+        n = 30000
+        plan = engine.plan(lanes, n)
+        assert "narrow build" in plan.kernel_name(vs.VS_KIND_SYNTH), fa
+        plan.close()
+        assert np.array_equal(engine.synth(lanes, n), po.synth(lanes, n)), fa
+        assert np.array_equal(engine.source(lanes, n), po.source(lanes, n)), fa
+    lane, dur = vs.lane_from_cli(["-r", "192000", "-d", "0.6", "-f", "50", "-g", "52", "-j", "5"], ["-v", "a"], 1)
     with pytest.raises(vs.VsError) as e:
         engine.synth([lane], 1000)
     assert e.value.code == vs._ffi.VS_ERR_UNSUPPORTED

@@ -301,9 +301,9 @@ extern "C" void vs_cos_row(int T2, double *row)
  * up, which keeps both the rounds and the super-steps well attended; the policy table below
  * comes from replaying real period sequences through the scheduler.
  * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
-extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
+static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min)
 {
-  const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (VS_WAVE * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
+  const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (group_lanes * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
   /* one super-step + the longest cycle + the slots a trip may run past the cycle */
   const int need = ((VS_SS + tmax + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
   if (need > hard_limit) return VS_ERR_UNSUPPORTED;
@@ -324,7 +324,20 @@ extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
   return VS_OK;
 }
 
-extern "C" int vs_ring_slots_for(int tmax, int *slots) { return vs_ring_policy(tmax, 0, slots, nullptr); }
+/* a ring of 64 columns (one utterance per lane of a wavefront) */
+extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
+{
+  return vs_ring_policy_for(VS_WAVE, tmax, cap, slots, ready_min);
+}
+
+/* Ring capacity for periods up to tmax: the 64-column ring if it can take them, else the narrow one
+ * (VS_NARROW_LANES columns, four times the slots in the same LDS; *group_lanes says which). */
+extern "C" int vs_ring_slots_for(int tmax, int *slots)
+{
+  int rc = vs_ring_policy_for(VS_WAVE, tmax, 0, slots, nullptr);
+  if (rc == VS_ERR_UNSUPPORTED) rc = vs_ring_policy_for(VS_NARROW_LANES, tmax, 0, slots, nullptr);
+  return rc;
+}
 
 /* filter-only lane record: gain, pre-emphasis, coefficients, row, vowel -n fields; everything
  * of the source left zero.  Only the fields the reference's vowel reads are validated, so any
@@ -480,11 +493,22 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
    * The one-wave kernel remains for the source-only and filter-only kinds, the per-cycle log, the
    * vowel -n power sums, and rings too long for a pair to fit the LDS. */
   const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
-  const unsigned grid = (unsigned)((n_lanes + VS_WAVE - 1) / VS_WAVE);
+  /* Utterances per wavefront: 64 -- unless the longest period of the batch does not fit a 64-column
+   * ring (the reference takes any rate but an explicit 22050, flowgen_shimmer.c:535-540, and sizes
+   * its buffer by the period, fg:569): then the narrow build of the one-wave kernel serves 16
+   * utterances per wavefront on a ring with four times the slots.  Slow (three quarters of every
+   * wavefront idle), but it synthesises what used to be VS_ERR_UNSUPPORTED. */
+  int group_lanes = VS_WAVE;
+  if (!filter_only) {
+    int probe = 0;
+    if (vs_ring_policy_for(VS_WAVE, tmax, 0, &probe, nullptr) == VS_ERR_UNSUPPORTED) group_lanes = VS_NARROW_LANES;
+  }
+  const size_t G = (size_t)group_lanes;
+  const unsigned grid = (unsigned)((n_lanes + G - 1) / G);
   int wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_WS) wave_specialised = 1;
   if (tune.kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
-  if (filter_only || wide) wave_specialised = 0;
+  if (filter_only || wide || group_lanes != VS_WAVE) wave_specialised = 0;
   /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
   std::vector<double> awide;
   if (wide) {
@@ -504,14 +528,14 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
   int cap = 0; /* default: four workgroups per CU */
-  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (VS_WAVE * 2)) - VS_TRASH_ROWS;
+  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (group_lanes * 2)) - VS_TRASH_ROWS;
   if (tune.ring_slots > 0) cap = tune.ring_slots;
   int slots = 0, ready_min = 32;
   int ltab_entries = 0;
   size_t lds_bytes = 0;
   int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2;
   if (!filter_only) {
-    int rc = vs_ring_policy(tmax, cap, &slots, &ready_min);
+    int rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min);
     if (rc != VS_OK) return rc;
     /* Super-step threshold, per 64-utterance group, from how many of the group's longest cycles
      * its ring holds (rho): a group whose ring holds barely one cycle cannot wait for all of its
@@ -522,23 +546,23 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
      * bottleneck and only runs full super-steps if the ring is deep enough (rho >= 1.65: BASELINE
      * config 3), three quarters otherwise (the long periods of config 5's F0 sweep). */
     const bool ws_shared_simd = wave_specialised && grid > 2u * cus;
-    for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
+    for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
       int tb = 1;
-      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) tb = std::max(tb, (int)dl[l].tbound);
+      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) tb = std::max(tb, (int)dl[l].tbound);
       const double rho = (double)(slots - VS_SS) / (double)tb;
       int thr = 32;
       if (rho >= 1.65) thr = 64;
       else if (rho >= 1.45) thr = 58;
       else if (rho >= 1.33) thr = 48;
       if (wave_specialised) thr = ws_shared_simd ? (rho >= 1.65 ? 64 : 48) : 40;
-      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) dl[l].ready_min = thr;
+      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) dl[l].ready_min = thr;
     }
     ready_min = tune.ready_min > 0 ? tune.ready_min : 0; /* 0: the groups' own thresholds */
     /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
      * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
-    for (size_t w0 = 0; w0 < n_lanes; w0 += VS_WAVE) {
+    for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
       int seen[VS_WAVE], nseen = 0, sum = 0;
-      for (size_t l = w0; l < n_lanes && l < w0 + VS_WAVE; l++) {
+      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) {
         bool dup = false;
         for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
         if (!dup) {
@@ -549,7 +573,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       if (sum > ltab_entries) ltab_entries = sum;
     }
     /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
-    lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * VS_WAVE * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+    lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
     if (lds_bytes > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
     /* wave-specialised launch shape: one pair = ring + cos rows + the two progress arrays; two
      * pairs per workgroup when that gives one workgroup per CU AND both fit the CU's LDS; when
@@ -594,6 +618,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
+  p->group_lanes = group_lanes;
   p->ws_pair_bytes = ws_pair_bytes;
   p->filter_only = filter_only;
   p->pre1 = pre1 ? 1 : 0;
@@ -714,8 +739,8 @@ extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t
   if (ws)
     snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, pre1 ? "true" : "false", p->ws_roles);
   else
-    snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
-             pre1 ? "true" : "false");
+    snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
+             pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");
   return VS_OK;
 }
 
@@ -762,6 +787,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;
   a.ws_roles = p->ws_roles;
+  a.group_lanes = p->group_lanes;
   a.ws_pair_bytes = p->ws_pair_bytes;
   /* a generator round starts when gen_min/64 of the lanes that still need cycles have room -- or at
    * once when a lane is about to run its filter dry (fewer than gen_low samples buffered).  The

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #define VS_WAVE 64 /* lanes per wavefront on gfx950: one utterance per lane */
+#define VS_NARROW_LANES 16 /* utterances per wavefront of the narrow build (periods beyond the 64-column ring) */
 #define VS_SS 24   /* samples per filter super-step == size of the rotating y[] register window */
 
 /* device-side lane flags */
@@ -71,6 +72,7 @@ typedef struct VsKernelArgs {
   int ready_min;      /* > 0: super-step threshold for every group (vs_tuning); 0: each group's own VsDevLane.ready_min */
   int ws_pairs;       /* wave-specialised kernels: groups of 64 utterances per workgroup (1, 2 or 4) */
   int ws_roles;       /* wavefronts per group: 2 (generator | filter) or 3 (open phase | noise | filter) */
+  int group_lanes;    /* utterances per wavefront of the one-wave kernel: 64 (or 0), or 16 = the narrow build for long periods */
   int ws_pair_bytes;  /* LDS bytes of one pair: ring + trash row + cos rows + progress words, 16-byte multiple */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
   float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */

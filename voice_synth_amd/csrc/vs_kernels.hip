@@ -275,10 +275,21 @@ __device__ __forceinline__ int vs_isqrt_floor(double v)
  * hit every bank eight times over and the generator alone runs 15 % longer; measured in round 3,
  * profiles/r03_kernel_experiments.txt.)
  */
-#define VS_RING_STEP (VS_WAVE * 2)    /* bytes from a lane's slot s to its slot s + 1 */
+/* utterances per group = lanes that own a ring column.  64, a whole wavefront -- except in the second
+ * build of this file (vs_kernels_narrow.o, -DVS_GROUP_LANES=16), which exists for periods too long for a
+ * 64-column ring (e.g. 48 kHz at F0 = 50 Hz with jitter: 1152 samples): a quarter of the columns, four
+ * times the slots in the same LDS, three quarters of the wavefront idle.  Slow, and only ever used for
+ * plans the wide ring cannot take (vs_plan_create); the reference accepts such rates
+ * (flowgen_shimmer.c:535-540) and sizes its buffer by the period (fg:569). */
+#ifndef VS_GROUP_LANES
+#define VS_GROUP_LANES VS_WAVE
+#else
+#define vs_synth_kernel vs_synth_kernel_narrow /* the two builds end up in one library: no shared kernel names */
+#endif
+#define VS_RING_STEP (VS_GROUP_LANES * 2) /* bytes from a lane's slot s to its slot s + 1 */
 
 /* int16 index of ring slot `slot` (0 <= slot < C + 8; slots [C, C + 8) are the trash rows) */
-__device__ __forceinline__ int vs_ring_idx(int slot, int lane) { return slot * VS_WAVE + lane; }
+__device__ __forceinline__ int vs_ring_idx(int slot, int lane) { return slot * VS_GROUP_LANES + lane; }
 
 /* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
  * at most once (wpos < C, i < C + VS_TRASH_ROWS). */
@@ -1000,7 +1011,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
     /* the first 8 now, the rest in two more batches issued from inside the sample loop (each a
      * chunk ahead of its use): 24 ring samples held at once are 16 registers too many */
 #pragma unroll
-    for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_WAVE];
+    for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
   }
 
   /* results leave in chunks of 8 samples = one 16-byte store, as soon as a chunk is complete: 24
@@ -1025,7 +1036,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
 
   if (KIND == VS_KIND_SOURCE) {
 #pragma unroll
-    for (int t = 8; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_WAVE];
+    for (int t = 8; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t]; /* the flow itself */
 #pragma unroll
@@ -1038,7 +1049,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
     for (int t = 0; t < VS_SS; ++t) {
       if (KIND != VS_KIND_FILTER && (t & 7) == 0 && t + 8 < VS_SS) {
 #pragma unroll
-        for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_WAVE];
+        for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
       }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
       double acc = (double)xin[t] * gain;
@@ -1150,8 +1161,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   extern __shared__ __attribute__((aligned(16))) int16_t ring[];
 
   const int lane = (int)threadIdx.x;
-  const long gl = (long)blockIdx.x * VS_WAVE + lane;
-  const bool valid = gl < (long)args.n_lanes;
+  const long gl = (long)blockIdx.x * VS_GROUP_LANES + lane;
+  const bool valid = (lane < VS_GROUP_LANES) && (gl < (long)args.n_lanes);
   const VsDevLane *__restrict__ L = args.lanes + (valid ? gl : (long)args.n_lanes - 1);
   const int N = args.n_samples;
   const int C = args.ring_slots;
@@ -1172,7 +1183,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 
   VsCfg c;
   VsGen s;
-  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_WAVE); /* slots [C, C+8) are the trash granule */
+  double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_GROUP_LANES); /* slots [C, C+8) are the trash rows */
   if (KIND != VS_KIND_FILTER) {
     vs_load_cfg(L, c, s);
     vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
@@ -1233,7 +1244,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
     /* ---- filter super-steps: a lane runs while it holds 24 buffered samples (or its tail) ---- */
     if (ready) {
       int outv[VS_SS];
-      vs_superstep<ARITH, KIND, PRE1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, irow, orow, n, N,
+      vs_superstep<ARITH, KIND, PRE1>(a, y, gain, pre, ring + rslot * VS_GROUP_LANES + lane, irow, orow, n, N,
                                       args.vec_ok != 0, outv, xpre);
       if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
@@ -1274,6 +1285,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   if (KIND != VS_KIND_FILTER && args.ncyc && valid) args.ncyc[row] = s.cyc;
 }
 
+#if VS_GROUP_LANES == VS_WAVE /* the narrow build holds the one-wave kernel only */
 /*
  * Wave-specialised fused kernels: the same 64 utterances are served by SEVERAL wavefronts, each with
  * one job, coupled through the LDS ring and a few per-lane progress words.  This is what the fused
@@ -1995,6 +2007,8 @@ extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_
   return hipGetLastError();
 }
 
+#endif /* VS_GROUP_LANES == VS_WAVE */
+
 /* ------------------------------------------------------------------------------------------
  * launch table
  * ---------------------------------------------------------------------------------------- */
@@ -2007,14 +2021,27 @@ static vs_kernel_fn vs_pick_log(bool log)
              : (vs_kernel_fn)vs_synth_kernel<ARITH, KIND, false, PRE1>;
 }
 
+#if VS_GROUP_LANES == VS_WAVE
+extern "C" hipError_t vs_launch_kernel_narrow(int arith, int kind, bool log, bool pre1, const VsKernelArgs *args,
+                                              unsigned grid, size_t lds_bytes, hipStream_t stream);
+#define VS_LAUNCH_NAME vs_launch_kernel
+#else
+#define VS_LAUNCH_NAME vs_launch_kernel_narrow_impl
+#endif
+
 /* pre1: every lane has pre_emphasis == 1.0 (the plan knows); only the exact filter has a
  * shorter sequence for it, the other kinds share one instantiation */
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1,
-                                       const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
-                                       hipStream_t stream)
+extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_specialised, bool pre1,
+                                     const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
+                                     hipStream_t stream)
 {
   vs_kernel_fn fn = nullptr;
   unsigned block = VS_WAVE;
+#if VS_GROUP_LANES == VS_WAVE
+  if (args->group_lanes != 0 && args->group_lanes != VS_WAVE) {
+    /* periods beyond the 64-column ring: the narrow build of this file (16 utterances per wavefront) */
+    return vs_launch_kernel_narrow(arith, kind, log, pre1, args, grid, lds_bytes, stream);
+  }
   if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
     const bool three = args->ws_roles == 3;
     if (arith == VS_ARITH_EXACT) {
@@ -2028,7 +2055,9 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_
     block = (unsigned)args->ws_roles * VS_WAVE * (unsigned)args->ws_pairs;
     lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
-  } else if (arith == VS_ARITH_EXACT) {
+  } else
+#endif
+  if (arith == VS_ARITH_EXACT) {
     if (kind == VS_KIND_SYNTH) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, true>(log) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, false>(log);
     else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
     else if (kind == VS_KIND_FILTER) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, true>(false) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, false>(false);
@@ -2047,3 +2076,11 @@ extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_
   hipLaunchKernelGGL(fn, dim3(grid), dim3(block), lds_bytes, stream, *args);
   return hipGetLastError();
 }
+
+#if VS_GROUP_LANES != VS_WAVE
+extern "C" hipError_t vs_launch_kernel_narrow(int arith, int kind, bool log, bool pre1, const VsKernelArgs *args,
+                                              unsigned grid, size_t lds_bytes, hipStream_t stream)
+{
+  return vs_launch_kernel_narrow_impl(arith, kind, log, false, pre1, args, grid, lds_bytes, stream);
+}
+#endif
