@@ -7,6 +7,9 @@
 #   tools/gpu.sh bench [bench.py args...]       bench.py, JSON line to gpurun_out/bench.json
 #   tools/gpu.sh prof <tag> [bench.py args...]  rocprofv3 kernel trace of bench.py -> gpurun_out/prof_<tag>/
 #   tools/gpu.sh pmc <tag> <counters...>        one rocprofv3 --pmc pass of bench.py per invocation
+#   tools/gpu.sh traffic <key> <kernel> [args]  FETCH_SIZE + WRITE_SIZE passes -> profiles/pmc_traffic.json[key]
+#   tools/gpu.sh sq <key> <kernel> [args]       SQ counter passes -> profiles/pmc_valu.json[key]
+#   tools/gpu.sh smoke                          __graft_entry__.smoke()
 # Steps may be chained:  tools/gpu.sh test -- ab default r2 -- bench
 # Boxes differ by up to 10 % in sustained clock, so variants are only ever compared within one call.
 set -o pipefail
@@ -40,6 +43,23 @@ run_step() {
     pmc)
       local tag="$1"; shift
       ( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/pmc_$tag" -o "$tag" --output-format csv -- python3 "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$tag.json" 2> "$OLDPWD/gpurun_out/pmc_$tag.err" ) || { tail -5 gpurun_out/pmc_$tag.err; return 1; } ;;
+    smoke)
+      timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+      local rc=$?; tail -3 gpurun_out/smoke.log; return $rc ;;
+    traffic)
+      # HBM bytes per launch: two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE), then profiles/pmc_traffic.json
+      #   tools/gpu.sh traffic <key> <kernel substring> [bench.py args...]      VS_LIB selects a variant library
+      local key="$1" kern="$2"; shift 2
+      for C in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d "$OLDPWD/gpurun_out/pmc_$C" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1 ) || { tail -5 gpurun_out/pmc_$C.log; return 1; }
+      done
+      python tools/summarize_pmc.py traffic gpurun_out/pmc_FETCH_SIZE/bench_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/bench_counter_collection.csv "$key" "$kern" ;;
+    sq)
+      # SQ counters per launch (two passes), then profiles/pmc_valu.json:  tools/gpu.sh sq <key> <kernel substring> [bench.py args...]
+      local key="$1" kern="$2"; shift 2
+      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq1" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq1.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq1.log; return 1; }
+      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq2" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq2.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq2.log; return 1; }
+      python tools/summarize_pmc.py valu gpurun_out/pmc_sq1/bench_counter_collection.csv gpurun_out/pmc_sq2/bench_counter_collection.csv "$key" --kernel "$kern" ;;
     *) echo "unknown step $step"; return 2 ;;
   esac
 }
