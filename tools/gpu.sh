@@ -53,13 +53,15 @@ run_step() {
       for C in FETCH_SIZE WRITE_SIZE; do
         ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d "$OLDPWD/gpurun_out/pmc_$C" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1 ) || { tail -5 gpurun_out/pmc_$C.log; return 1; }
       done
-      python tools/summarize_pmc.py traffic gpurun_out/pmc_FETCH_SIZE/bench_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/bench_counter_collection.csv "$key" "$kern" ;;
+      python tools/summarize_pmc.py traffic gpurun_out/pmc_FETCH_SIZE/bench_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/bench_counter_collection.csv "$key" "$kern" || return 1
+      cp profiles/pmc_traffic.json gpurun_out/ ;;   # only gpurun_out/ travels back: copy it into profiles/ by hand
     sq)
       # SQ counters per launch (two passes), then profiles/pmc_valu.json:  tools/gpu.sh sq <key> <kernel substring> [bench.py args...]
       local key="$1" kern="$2"; shift 2
       ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq1" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq1.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq1.log; return 1; }
       ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq2" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq2.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq2.log; return 1; }
-      python tools/summarize_pmc.py valu gpurun_out/pmc_sq1/bench_counter_collection.csv gpurun_out/pmc_sq2/bench_counter_collection.csv "$key" --kernel "$kern" ;;
+      python tools/summarize_pmc.py valu gpurun_out/pmc_sq1/bench_counter_collection.csv gpurun_out/pmc_sq2/bench_counter_collection.csv "$key" --kernel "$kern" || return 1
+      cp profiles/pmc_valu.json gpurun_out/ ;;
     *) echo "unknown step $step"; return 2 ;;
   esac
 }

@@ -1089,11 +1089,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         qlo = (olo > qlo) ? olo : qlo;
       }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
-#ifdef VS_EXP_STORE_AT_END
-      if (t == VS_SS - 1) { put8(0); put8(1); put8(2); }
-#else
       if ((t & 7) == 7) put8(t >> 3);
-#endif
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
       __builtin_amdgcn_sched_barrier(0);
