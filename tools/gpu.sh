@@ -10,6 +10,10 @@
 #   tools/gpu.sh traffic <key> <kernel> [args]  FETCH_SIZE + WRITE_SIZE passes -> profiles/pmc_traffic.json[key]
 #   tools/gpu.sh sq <key> <kernel> [args]       SQ counter passes -> profiles/pmc_valu.json[key]
 #   tools/gpu.sh smoke                          __graft_entry__.smoke()
+#   tools/gpu.sh roles [config] [lanes]         two-role against three-role kernel (+ timing-only builds)
+#   tools/gpu.sh sweep <roles> [config] [lanes] generator round-start knobs
+#   tools/gpu.sh diag                           phase breakdown from the diagnostic build
+#   tools/gpu.sh full <tag>                     the round's evidence pass (copy the summaries into profiles/)
 # Steps may be chained:  tools/gpu.sh test -- ab default r2 -- bench
 # Boxes differ by up to 10 % in sustained clock, so variants are only ever compared within one call.
 set -o pipefail
@@ -62,6 +66,40 @@ run_step() {
       ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq2" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq2.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq2.log; return 1; }
       python tools/summarize_pmc.py valu gpurun_out/pmc_sq1/bench_counter_collection.csv gpurun_out/pmc_sq2/bench_counter_collection.csv "$key" --kernel "$kern" || return 1
       cp profiles/pmc_valu.json gpurun_out/ ;;
+    roles)
+      # two-role against three-role wave-specialised kernel (and the timing-only builds, if present:
+      # `make variant NAME=gonly DEFS=-DVS_TIMING_GENERATOR_ONLY`, `NAME=fonly DEFS=-DVS_TIMING_FILTER_ONLY`)
+      local cfg=${1:-3} lanes=${2:-65536}
+      for rep in 1 2; do for lib in libvoicesynth.so libvoicesynth_gonly.so libvoicesynth_fonly.so; do
+        [ -f voice_synth_amd/lib/$lib ] || continue
+        for roles in 2 3; do
+          echo "== rep $rep $lib roles $roles"
+          VS_LIB=$lib VS_DEBUG_TUNING=1 VS_WS_ROLES=$roles timeout -k 10 120 python tools/quick_bench.py $cfg $lanes 5 | grep -E "exact/synth|fma/synth"
+        done
+      done; done ;;
+    sweep)
+      # round-start knobs of the generator (vs_tuning.gen_min x gen_low):  tools/gpu.sh sweep <roles> [config] [lanes]
+      local roles=${1:-3} cfg=${2:-3} lanes=${3:-65536}
+      for gm in ${GEN_MINS:-32 48 56 64}; do for gl in ${GEN_LOWS:-32 48 72}; do
+        echo -n "roles $roles gen_min $gm gen_low $gl: "
+        VS_DEBUG_TUNING=1 VS_WS_ROLES=$roles VS_GEN_MIN=$gm VS_GEN_LOW=$gl timeout -k 10 120 python tools/quick_bench.py $cfg $lanes 4 | grep -E "exact/synth|fma/synth" | awk '{printf "%s %s ms   ", $1, $2}'; echo
+      done; done ;;
+    diag)
+      # phase breakdown of the wave-specialised kernels from the diagnostic build (`make diag`)
+      timeout -k 10 200 python tools/diag_ws.py | tee gpurun_out/diag_ws.txt ;;
+    full)
+      # the round's evidence pass: tests, smoke, kernel trace, traffic and SQ counters (exact + fma), bench
+      local tag=${1:-r03}
+      run_step test || return 1
+      run_step smoke || return 1
+      run_step prof ${tag}_bench --no-cpu-baseline || return 1
+      cp "$(find gpurun_out/prof_${tag}_bench -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_kernel_stats.csv
+      run_step traffic config3_exact_65536 "vs_synth_ws_kernel<0" || return 1
+      run_step traffic config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
+      run_step sq config3_exact_65536 "vs_synth_ws_kernel<0" || return 1
+      run_step sq config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
+      run_step bench || return 1
+      cp gpurun_out/bench.json gpurun_out/${tag}_bench_n1.json ;;
     *) echo "unknown step $step"; return 2 ;;
   esac
 }
