@@ -78,3 +78,7 @@ $(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_na
 variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels.hip
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread -ldl
+
+# device listing of the shipped kernels (same flags) for tools/isa_loops.py
+isa:
+	mkdir -p build && $(HIPCC) $(HIPFLAGS) -Iinclude -I$(CSRC) -S --cuda-device-only -o build/vs_kernels.s $(CSRC)/vs_kernels.hip

@@ -614,6 +614,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->d_diag = nullptr;
   p->d_err = nullptr;
   p->d_opow = nullptr;
+  p->d_sink = nullptr;
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
@@ -634,6 +635,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab.size() + 1) * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+  if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
   if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, awide.size() * sizeof(double));
@@ -666,6 +668,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (p->d_lanes) (void)hipFree(p->d_lanes);
     if (p->d_costab) (void)hipFree(p->d_costab);
     if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_sink) (void)hipFree(p->d_sink);
     if (p->d_opow) (void)hipFree(p->d_opow);
     if (p->d_awide) (void)hipFree(p->d_awide);
     if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
@@ -692,6 +695,7 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_lanes) (void)hipFree(p->d_lanes);
   if (p->d_costab) (void)hipFree(p->d_costab);
   if (p->d_err) (void)hipFree(p->d_err);
+  if (p->d_sink) (void)hipFree(p->d_sink);
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_awide) (void)hipFree(p->d_awide);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
@@ -783,6 +787,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.ready_min = p->ready_min;
   a.diag = p->d_diag;
   a.err = p->d_err;
+  a.sink = p->d_sink;
   a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;

@@ -83,6 +83,7 @@ typedef struct VsKernelArgs {
   int fault;          /* VS_FAULT_* (tests only) */
   int ws_filter_prio; /* wave-specialised kernel: s_setprio of the filter wave (0 = leave at 0) */
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
+  int16_t *sink;       /* one row of n_samples + 32 samples nobody reads: where the lanes beyond n_lanes of the last group store (wave-specialised kernels) */
   const double *awide; /* wide plans (a coefficient set of 23..40 taps): A[1..40] per lane record, zeros behind its order */
 } VsKernelArgs;
 

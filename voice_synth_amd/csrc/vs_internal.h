@@ -58,6 +58,7 @@ struct vs_plan {
   unsigned grid;
   unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
   int *d_err;                 /* spin-limit word of the wave-specialised kernel */
+  int16_t *d_sink;            /* VsKernelArgs.sink */
   float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
   long opow_pitch;
   int wave_specialised;

@@ -304,6 +304,8 @@ __device__ __forceinline__ int vs_ring_at(int wpos, int C, int i, int lane)
 /* Eight consecutive ring slots of a lane that start ANYWHERE (the noise trips follow the Philox
  * blocks, not the ring): the run wraps at most once, after kw slots.  A sample costs one compare,
  * one select and the store (the slot offset W*128 sits in the store's immediate). */
+typedef __attribute__((address_space(3))) char vs_lds_char;
+typedef __attribute__((address_space(3))) int16_t vs_lds_i16;
 struct VsRun8 {
   char *A, *B; /* LDS address of slot 0 of the run before / after the wrap */
   int kw;      /* slots before the wrap (>= 8: none in this run) */
@@ -537,18 +539,18 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
     for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
     /* a lane that is done sends the trip to the trash rows */
     char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
+    /* the eight store addresses first, once (one compare and one select each: the ring may wrap inside
+     * the trip), then -- rarely -- the end of the cycle, then the stores */
+    vs_lds_char *pw[8]; /* typed as LDS: through an array of generic pointers the stores would turn into flat ones */
+#pragma unroll
+    for (int w = 0; w < 8; ++w) pw[w] = (vs_lds_char *)((w < run.kw) ? A : B);
     if (TAIL && __any((q0 < m) && (q0 + 8 > m))) {
       /* some lane ends inside this trip: its slots behind the end go to the trash rows too */
 #pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        char *pw = (w < run.kw) ? A : B;
-        pw = (q0 + w < m) ? pw : trashA;
-        *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
-      }
-    } else {
-#pragma unroll
-      for (int w = 0; w < 8; ++w) *(int16_t *)(((w < run.kw) ? A : B) + w * VS_RING_STEP) = (int16_t)xv[w];
+      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : (vs_lds_char *)trashA;
     }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) *(vs_lds_i16 *)(pw[w] + w * VS_RING_STEP) = (int16_t)xv[w];
     q0 += 8;
     b += 2u;
     vs_run8_advance(run, C);
@@ -628,29 +630,44 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
   int T4 = s.T4;
   /* the short sequences: every active lane proved in range on the host, no per-cycle log */
   const bool fast = !LOG && __all((c.flags & VS_DF_FAST) != 0);
+  constexpr bool PREFETCH = !SPLIT;
 
   /* ---- rising half-pulse: fg:318-324 ---- */
   if (fast) {
     const float dcs2 = dcsf * dcsf;
-    /* the cos values of trip i+8 are read while trip i computes: one wavefront per SIMD has
-     * nothing else to put behind an LDS round trip */
+    /* PREFETCH (a wavefront with a SIMD of its own, or one that does whole cycles): the cos values of
+     * trip i+8 are read while trip i computes -- nothing else would hide the LDS round trip.  The
+     * open-phase wavefront of the three-role kernel reads them where it needs them instead: it shares
+     * its SIMD with two others that issue while it waits, and carrying the next trip's values costs a
+     * register copy per value and trip (every instruction counts, see vs_generator_wave). */
     double cv[8];
+    if (PREFETCH) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) cv[k] = trow[k];
+      for (int k = 0; k < 8; ++k) cv[k] = trow[k];
+    }
     for (int i = 0; __any(i < T2); i += 8) {
       if (i < T2) {
         double nv[8];
-        if (i + 8 < T2) {
+        if (PREFETCH) {
+          if (i + 8 < T2) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) nv[k] = trow[i + 8 + k];
+            for (int k = 0; k < 8; ++k) nv[k] = trow[i + 8 + k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) cv[k] = trow[i + k];
         }
         int x[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ah * (1.0 - cv[k])); /* pad: cos = 1 -> 0 */
+        if (PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) cv[k] = nv[k];
+          for (int k = 0; k < 8; ++k) cv[k] = nv[k];
+        }
         const VsRun8 run = vs_run8(ring, s.wpos, C, i, lane);
-        /* monotone flank: if the trip's first sample is not below DC none of it is */
+        /* monotone flank: if the trip's first sample is not below DC none of it is.  (The stores are
+         * written out in both branches: joined behind them, the samples of the common branch would be
+         * copied into the registers the rare one leaves them in.) */
         if (__any(x[0] < c.thr)) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
@@ -660,11 +677,14 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
             const float acc = psum + vs_sq_f(x[k]);
             psum = lt ? dcs2 : acc;
           }
+          vs_run8_store_all(run, x);
+          asm volatile("; rising trip with samples below DC"); /* two different tails: nothing to merge again */
         } else {
 #pragma unroll
           for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
+          vs_run8_store_all(run, x);
+          asm volatile("; rising trip");
         }
-        vs_run8_store_all(run, x);
       }
     }
   } else {
@@ -726,7 +746,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
        * sample is not below DC holds no break.  Stores are unconditional: slots at and behind
        * the break are written again by the closed phase (2*T2 + 8 <= T). */
       double cv[8];
-      if (8 <= T2) {
+      if (PREFETCH && (8 <= T2)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) cv[k] = trow[k];
       }
@@ -734,15 +754,22 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         if (run && (k0 + 8 <= T2)) {
           kdone = k0 + 8;
           double nv[8];
-          if (k0 + 16 <= T2) { /* next trip's cos values, read behind this trip's arithmetic */
+          if (PREFETCH) {
+            if (k0 + 16 <= T2) { /* next trip's cos values, read behind this trip's arithmetic */
 #pragma unroll
-            for (int k = 0; k < 8; ++k) nv[k] = trow[k0 + 8 + k];
+              for (int k = 0; k < 8; ++k) nv[k] = trow[k0 + 8 + k];
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cv[k] = trow[k0 + k];
           }
           int x[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ad * ((Kd * cv[k] - Kd) + 1.0));
+          if (PREFETCH) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) cv[k] = nv[k];
+            for (int k = 0; k < 8; ++k) cv[k] = nv[k];
+          }
           const VsRun8 r8 = vs_run8(ring, s.wpos, C, T2 + k0, lane);
           if (__any(x[7] < c.thr)) {
 #pragma unroll
@@ -752,11 +779,14 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
               run = run && !brk;
               psum = run ? (psum + vs_sq_f(x[k])) : psum;
             }
+            vs_run8_store_all(r8, x);
+            asm volatile("; falling trip with the break");
           } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
+            vs_run8_store_all(r8, x);
+            asm volatile("; falling trip");
           }
-          vs_run8_store_all(r8, x);
         }
       }
     }
@@ -982,7 +1012,7 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
  * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
  * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
  */
-template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false>
+template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
@@ -990,7 +1020,9 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
                                              int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8],
                                              bool store_ok = true)
 {
-  const bool whole = vec_ok && (n + VS_SS <= N);
+  /* WHOLE: the caller has taken this decision out of its loop (1: 16-byte stores, 0: sample by sample).
+   * With it -- and store_ok a constant -- nothing branches between the ring reads and their use. */
+  const bool whole = (WHOLE < 0) ? (vec_ok && (n + VS_SS <= N)) : (WHOLE != 0);
   int xin[VS_SS];
   if (KIND == VS_KIND_FILTER) {
     if (whole) {
@@ -1052,7 +1084,12 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
       }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-      double acc = (double)xin[t] * gain;
+      int xi = xin[t];
+      /* the sample as a 32-bit integer HERE: left alone the compiler converts int16 -> double in one go,
+       * which it then lowers to a zero-extending ring read + V_BFE_I32 + convert instead of DS_READ_I16 +
+       * convert (16 of 24 samples, 0.7 instructions per sample) */
+      if (KIND != VS_KIND_FILTER) asm volatile("" : "+v"(xi));
+      double acc = (double)xi * gain;
       const double y1 = y[(t + VS_SS - 1) % VS_SS];
       if (ARITH == VS_ARITH_EXACT) {
         /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
@@ -1363,24 +1400,43 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
   vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
   int spins = 0;
-  for (;;) {
-    /* tests (vs_tuning.fault): a generator that never publishes -- the bounded waits of the other
-     * wavefronts must run out and reach the caller as VS_ERR_INTERNAL */
-    if (args.fault == VS_FAULT_WITHHOLD_PROGRESS) break;
-    const bool need = g.valid && (s.g < N);
-    if (!__any(need)) break;
-    if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
+  /* A poll that cannot end differently from the last one is cut short: whether a round starts depends
+   * on this wavefront's own state (which only a round changes) and on two words per lane written by
+   * the others -- npub and, three roles, otak.  While neither has moved the wavefront goes back to
+   * sleep after two LDS reads and a compare instead of the ~30 instructions of the full evaluation;
+   * an idle open-phase wavefront polls ~2000 times per launch, and every instruction it issues is
+   * taken from the two that work (profiles/r03_kernel_experiments.txt). */
+  int prev_seen = -1, prev_taken = -1;
+  bool dirty = true; /* own state changed since the last full evaluation */
+  /* tests (vs_tuning.fault): a generator that never publishes -- the bounded waits of the other
+   * wavefronts must run out and reach the caller as VS_ERR_INTERNAL */
+  const bool withhold = args.fault == VS_FAULT_WITHHOLD_PROGRESS;
+  while (!withhold) {
 #ifdef VS_TIMING_GENERATOR_ONLY
     const int n_seen = s.g; /* timing build: the generator alone, never short of room */
 #else
     const int n_seen = __hip_atomic_load(&g.npub[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-    bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
-    if (SPLIT) {
-      /* ... and one of the lane's order boxes is free */
-      const int taken = __hip_atomic_load(&g.ord.otak[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      want = want && (s.posted - taken < VS_ORDER_DEPTH);
+    int taken = 0;
+    if (SPLIT) taken = __hip_atomic_load(&g.ord.otak[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (!dirty && !__any((n_seen != prev_seen) || (taken != prev_taken))) {
+      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      VS_DIAG_ADD(dg, 6)
+      if (++spins > args.spin_limit) {
+        if (args.err && lane == 0) atomicOr(args.err, 1);
+        break;
+      }
+      continue;
     }
+    prev_seen = n_seen;
+    prev_taken = taken;
+    dirty = false;
+    const bool need = g.valid && (s.g < N);
+    if (!__any(need)) break;
+    if (need && !s.pend) vs_cycle_scalars(c, s, dg); /* fixes the next period s.T */
+    bool want = need && (s.g - n_seen + s.T + VS_TRASH_ROWS <= C);
+    /* ... and, three roles, one of the lane's order boxes is free */
+    if (SPLIT) want = want && (s.posted - taken < VS_ORDER_DEPTH);
     const bool hungry = want && (s.g - n_seen < args.gen_low); /* its filter would run dry during a round */
     const int n_need = __builtin_popcountll(__ballot(need));
     const int n_want = __builtin_popcountll(__ballot(want));
@@ -1397,6 +1453,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
         __hip_atomic_store(&g.gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       spins = 0;
+      dirty = true;
     } else {
       __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
       VS_DIAG_ADD(dg, 6)
@@ -1510,7 +1567,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
   for (int j = 1; j <= VS_ORDER; ++j) a[j] = L->a[j - 1];
   const double gain = L->gain;
   const double pre = L->pre;
-  int16_t *__restrict__ orow = args.out + g.row * args.out_pitch;
+  int16_t *orow = args.out + g.row * args.out_pitch;
   const int ready_min = (args.ready_min > 0) ? args.ready_min : __builtin_amdgcn_readfirstlane(L->ready_min);
 #ifdef VS_DIAG
   VsDiag dg;
@@ -1535,8 +1592,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
      * the old and the new window meet at the loop latch, and the compiler would copy it again. */
     bool gave_up = false;
     int rslot = 0;
-    for (int n = 0; n < N; n += VS_SS) {
-      VS_DIAG_ADD(dg, 7)
+    /* waits until every live lane holds the 24 samples from n on */
+    auto await = [&](int n) {
       for (int polls = 0; !gave_up; ++polls) {
 #ifdef VS_TIMING_FILTER_ONLY
         const int g_seen = N; /* timing build: the filter alone, never short of input */
@@ -1553,15 +1610,41 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      int outv[VS_SS];
-      vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                     N, args.vec_ok != 0, outv, xpre, valid);
+    };
+    /* the ring reads of the super-step precede this store in the LDS queue: the slots are free */
+    auto release = [&](int n_done) {
       rslot += VS_SS;
       if (rslot >= C) rslot = 0;
-      /* the ring reads above precede this store in the LDS queue: the slots are free */
       VS_LDS_RELEASE();
-      __hip_atomic_store(&npub[lane], n + VS_SS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&npub[lane], n_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    /* Lanes beyond n_lanes store to a row of their own that nobody reads, and the super-steps that
+     * store sample by sample (the last one of a length that is no multiple of 24; all of them when rows
+     * are not 4-byte aligned) run in a loop of their own: no branch is left inside a super-step, and
+     * without one the compiler keeps each ring read together with its sign extension (DS_READ_I16
+     * instead of DS_READ_U16 + V_BFE_I32: 16 instructions per super-step) and drops the exec masks
+     * around the 16-byte stores. */
+    if (!valid) orow = args.sink;
+    const int n_whole = (args.vec_ok != 0) ? (N / VS_SS) * VS_SS : 0;
+    int n = 0;
+    for (; n < n_whole; n += VS_SS) {
+      VS_DIAG_ADD(dg, 7)
+      await(n);
+      int outv[VS_SS];
+      vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                        N, true, outv, xpre, true);
+      release(n + VS_SS);
+      VS_DIAG_ADD(dg, 0)
+    }
+    for (; n < N; n += VS_SS) {
+      VS_DIAG_ADD(dg, 7)
+      await(n);
+      int outv[VS_SS];
+      vs_u32x4 xpre[VS_SS / 8];
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 0>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                        N, false, outv, xpre, true);
+      release(n + VS_SS);
       VS_DIAG_ADD(dg, 0)
     }
   } else {
