@@ -14,7 +14,7 @@ enum {
   O_MUL_F64 = 0, O_ADD_F64, O_FMA_F64, O_CHAIN, O_MAD_U64, O_MUL_LO, O_BITOP3, O_XOR, O_LSHR, O_CVT_F64_U32, O_CVT_I32_F64,
   O_CEIL_F64, O_CNDMASK, O_MUL24, O_CVT_F32_I32, O_ADD_F32, O_CVT_PK, O_PK_MAX, O_MIN_I32, O_MOV64, O_DSW16, O_DSW128,
   O_DSR64, O_DSR128, O_SALU, O_MIX_F64_XOR, O_MIX_F64_MAD, O_MIX_F64_SALU,
-  O_CND_SGPR, O_CMP_CND, O_CMP_VCC, O_CMP_SGPR, O_CMP_CND_SGPR, O_MAX_I32, O_MED3_I32, O_CND_AFTER_SMOV, O_ADD_U32, O_ADD_CO, O_COUNT
+  O_CND_SGPR, O_CMP_CND, O_CMP_VCC, O_CMP_SGPR, O_CMP_CND_SGPR, O_MAX_I32, O_MED3_I32, O_CND_AFTER_SMOV, O_ADD_U32, O_ADD_CO, O_MIX_F64_WAITCNT, O_MIX_F64_NOP, O_MIX_F64_3WAIT, O_COUNT
 };
 static const char *op_name[O_COUNT] = {
   "v_mul_f64", "v_add_f64", "v_fma_f64", "mul+add f64 dependent chain", "v_mad_u64_u32", "v_mul_lo_u32", "v_bitop3_b32", "v_xor_b32",
@@ -22,7 +22,8 @@ static const char *op_name[O_COUNT] = {
   "v_add_f32", "v_cvt_pk_i16_i32", "v_pk_max_i16", "v_min_i32", "v_mov_b64 (pair)", "ds_write_b16", "ds_write_b128",
   "ds_read_b64", "ds_read_b128", "s_add_u32", "1 v_mul_f64 : 1 v_xor_b32", "1 v_mul_f64 : 1 v_mad_u64_u32", "1 v_mul_f64 : 1 s_add_u32",
   "v_cndmask_b32 (sgpr pair mask)", "v_cmp vcc + v_cndmask vcc", "v_cmp_lt_u32 -> vcc", "v_cmp_lt_u32 -> sgpr pair", "v_cmp sgpr + v_cndmask sgpr",
-  "v_max_i32", "v_med3_i32", "v_cndmask_b32 vcc (vcc from s_mov)", "v_add_u32", "v_add_co_u32 (writes vcc)"};
+  "v_max_i32", "v_med3_i32", "v_cndmask_b32 vcc (vcc from s_mov)", "v_add_u32", "v_add_co_u32 (writes vcc)", "1 v_mul_f64 : 1 s_waitcnt (nothing pending)", "1 v_mul_f64 : 1 s_nop 0",
+  "3 v_mul_f64 : 1 s_waitcnt"};
 
 struct Regs {
   double a0, a1, a2, a3, b0, b1;
@@ -115,6 +116,12 @@ __device__ __forceinline__ void body(Regs &r, unsigned &sacc)
     REP16(asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4" : "+v"(r.u0), "+v"(r.u1), "+v"(r.u2), "+v"(r.u3) : "v"(r.w0));)
   } else if (O == O_ADD_CO) {
     REP16(asm volatile("v_add_co_u32 %0, vcc, %0, %4\n\tv_add_co_u32 %1, vcc, %1, %4\n\tv_add_co_u32 %2, vcc, %2, %4\n\tv_add_co_u32 %3, vcc, %3, %4" : "+v"(r.u0), "+v"(r.u1), "+v"(r.u2), "+v"(r.u3) : "v"(r.w0) : "vcc");)
+  } else if (O == O_MIX_F64_WAITCNT) {
+    REP16(asm volatile("v_mul_f64 %0, %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tv_mul_f64 %1, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "+v"(r.a0), "+v"(r.a1) : "v"(r.b0));)
+  } else if (O == O_MIX_F64_NOP) {
+    REP16(asm volatile("v_mul_f64 %0, %0, %2\n\ts_nop 0\n\tv_mul_f64 %1, %1, %2\n\ts_nop 0" : "+v"(r.a0), "+v"(r.a1) : "v"(r.b0));)
+  } else if (O == O_MIX_F64_3WAIT) {
+    REP16(asm volatile("v_mul_f64 %0, %0, %3\n\tv_mul_f64 %1, %1, %3\n\tv_mul_f64 %2, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "+v"(r.a0), "+v"(r.a1), "+v"(r.a2) : "v"(r.b0));)
   }
 }
 

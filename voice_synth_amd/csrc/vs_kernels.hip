@@ -353,6 +353,41 @@ __device__ __forceinline__ VsRun8 vs_run8_or_trash(bool emit, int16_t *ring, int
   return r;
 }
 
+/* The eight store addresses of a run: pw[w] = (w < kw) ? A : B as LDS byte addresses.  Written out as
+ * eight compares into eight SGPR pairs and then eight selects: on gfx950 a VALU instruction must not read
+ * a mask within two wait states of the VALU instruction that wrote it, and left to itself the compiler
+ * pairs every compare with its select and puts an s_nop between them -- eight instructions per trip that
+ * do nothing, each at the price of one that does (ubench5). */
+__device__ __forceinline__ uint32_t vs_lds_addr(const char *p) { return (uint32_t)(uintptr_t)(const vs_lds_char *)p; }
+__device__ __forceinline__ void vs_wrap_select8(uint32_t A, uint32_t B, int kw, uint32_t (&pw)[8])
+{
+  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
+  asm volatile("v_cmp_lt_i32_e64 %8, 0, %18\n\t"
+               "v_cmp_lt_i32_e64 %9, 1, %18\n\t"
+               "v_cmp_lt_i32_e64 %10, 2, %18\n\t"
+               "v_cmp_lt_i32_e64 %11, 3, %18\n\t"
+               "v_cmp_lt_i32_e64 %12, 4, %18\n\t"
+               "v_cmp_lt_i32_e64 %13, 5, %18\n\t"
+               "v_cmp_lt_i32_e64 %14, 6, %18\n\t"
+               "v_cmp_lt_i32_e64 %15, 7, %18\n\t"
+               "v_cndmask_b32_e64 %0, %17, %16, %8\n\t"
+               "v_cndmask_b32_e64 %1, %17, %16, %9\n\t"
+               "v_cndmask_b32_e64 %2, %17, %16, %10\n\t"
+               "v_cndmask_b32_e64 %3, %17, %16, %11\n\t"
+               "v_cndmask_b32_e64 %4, %17, %16, %12\n\t"
+               "v_cndmask_b32_e64 %5, %17, %16, %13\n\t"
+               "v_cndmask_b32_e64 %6, %17, %16, %14\n\t"
+               "v_cndmask_b32_e64 %7, %17, %16, %15"
+               : "=&v"(pw[0]), "=&v"(pw[1]), "=&v"(pw[2]), "=&v"(pw[3]), "=&v"(pw[4]), "=&v"(pw[5]), "=&v"(pw[6]), "=&v"(pw[7]),
+                 "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
+               : "v"(A), "v"(B), "v"(kw));
+}
+template <int W>
+__device__ __forceinline__ void vs_lds_store16(uint32_t addr, int v)
+{
+  *(vs_lds_i16 *)(addr + (uint32_t)(W * VS_RING_STEP)) = (int16_t)v;
+}
+
 template <int W>
 __device__ __forceinline__ void vs_run8_store(const VsRun8 &r, int v)
 {
@@ -369,8 +404,10 @@ __device__ __forceinline__ void vs_run8_store_if(const VsRun8 &r, char *trashA, 
 }
 __device__ __forceinline__ void vs_run8_store_all(const VsRun8 &r, const int (&x)[8])
 {
-  vs_run8_store<0>(r, x[0]); vs_run8_store<1>(r, x[1]); vs_run8_store<2>(r, x[2]); vs_run8_store<3>(r, x[3]);
-  vs_run8_store<4>(r, x[4]); vs_run8_store<5>(r, x[5]); vs_run8_store<6>(r, x[6]); vs_run8_store<7>(r, x[7]);
+  uint32_t pw[8];
+  vs_wrap_select8(vs_lds_addr(r.A), vs_lds_addr(r.B), r.kw, pw);
+  vs_lds_store16<0>(pw[0], x[0]); vs_lds_store16<1>(pw[1], x[1]); vs_lds_store16<2>(pw[2], x[2]); vs_lds_store16<3>(pw[3], x[3]);
+  vs_lds_store16<4>(pw[4], x[4]); vs_lds_store16<5>(pw[5], x[5]); vs_lds_store16<6>(pw[6], x[6]); vs_lds_store16<7>(pw[7], x[7]);
 }
 
 /*
@@ -541,16 +578,16 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
     char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
     /* the eight store addresses first, once (one compare and one select each: the ring may wrap inside
      * the trip), then -- rarely -- the end of the cycle, then the stores */
-    vs_lds_char *pw[8]; /* typed as LDS: through an array of generic pointers the stores would turn into flat ones */
-#pragma unroll
-    for (int w = 0; w < 8; ++w) pw[w] = (vs_lds_char *)((w < run.kw) ? A : B);
+    uint32_t pw[8];
+    vs_wrap_select8(vs_lds_addr(A), vs_lds_addr(B), run.kw, pw);
     if (TAIL && __any((q0 < m) && (q0 + 8 > m))) {
       /* some lane ends inside this trip: its slots behind the end go to the trash rows too */
+      const uint32_t trash32 = vs_lds_addr(trashA);
 #pragma unroll
-      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : (vs_lds_char *)trashA;
+      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : trash32;
     }
-#pragma unroll
-    for (int w = 0; w < 8; ++w) *(vs_lds_i16 *)(pw[w] + w * VS_RING_STEP) = (int16_t)xv[w];
+    vs_lds_store16<0>(pw[0], xv[0]); vs_lds_store16<1>(pw[1], xv[1]); vs_lds_store16<2>(pw[2], xv[2]); vs_lds_store16<3>(pw[3], xv[3]);
+    vs_lds_store16<4>(pw[4], xv[4]); vs_lds_store16<5>(pw[5], xv[5]); vs_lds_store16<6>(pw[6], xv[6]); vs_lds_store16<7>(pw[7], xv[7]);
     q0 += 8;
     b += 2u;
     vs_run8_advance(run, C);
@@ -1079,17 +1116,20 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
     uint32_t qlo = 0u;               /* unsigned maximum of their low words */
 #pragma unroll
     for (int t = 0; t < VS_SS; ++t) {
-      if (KIND != VS_KIND_FILTER && (t & 7) == 0 && t + 8 < VS_SS) {
+      if (KIND != VS_KIND_FILTER && (t & 7) == 0) {
+        if (t + 8 < VS_SS) {
 #pragma unroll
-        for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
+          for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
+        }
+        /* this chunk's eight samples are all "used" here: ONE s_waitcnt for the batch (the LDS answers in
+         * order) instead of one in front of every sample's first use -- to a wavefront that issues an
+         * instruction every ~5.3 ticks whatever it is, a wait that has nothing to wait for costs as much
+         * as a multiplication (tools/ubench/ubench5.hip) */
+        asm volatile("" ::"v"(xin[t]), "v"(xin[t + 1]), "v"(xin[t + 2]), "v"(xin[t + 3]), "v"(xin[t + 4]), "v"(xin[t + 5]),
+                     "v"(xin[t + 6]), "v"(xin[t + 7]));
       }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-      int xi = xin[t];
-      /* the sample as a 32-bit integer HERE: left alone the compiler converts int16 -> double in one go,
-       * which it then lowers to a zero-extending ring read + V_BFE_I32 + convert instead of DS_READ_I16 +
-       * convert (16 of 24 samples, 0.7 instructions per sample) */
-      if (KIND != VS_KIND_FILTER) asm volatile("" : "+v"(xi));
-      double acc = (double)xi * gain;
+      double acc = (double)xin[t] * gain;
       const double y1 = y[(t + VS_SS - 1) % VS_SS];
       if (ARITH == VS_ARITH_EXACT) {
         /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
