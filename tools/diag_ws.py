@@ -10,7 +10,9 @@ GN = ["jitter+shimmer", "rising", "Knew+falling", "closed", "noise", "bookkeepin
 FN = ["superstep+publish", "-", "-", "-", "-", "-", "sleep/poll", "poll+decide"]
 def main():
     n = 65536
-    specs, fs, dur, label = configs.config_specs(3, n)
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    specs, fs, dur, label = configs.config_specs(cfg, n)
+    print(label)
     lanes, d = vs.lanes_from_specs(specs); ns = vs.num_samples(fs, d)
     eng = vs.Engine(0); lib = vs.load()
     lib.vs_plan_set_diag.restype = C.c_int; lib.vs_plan_set_diag.argtypes = [C.c_void_p, C.c_void_p]
@@ -32,4 +34,11 @@ def main():
         for k in range(8):
             if names[k] != "-":
                 print("    %-18s %7.1f ticks/sample" % (names[k], part[:, k].mean() / ns))
+    # per group (groups are cut from the lanes sorted by period): where the slowest ones spend their time
+    wall = a[:, 8] + a[:, 14] + a[:, 15]
+    order = np.argsort(wall)
+    print("filter wavefront per group, ticks/sample: wall min %.0f median %.0f max %.0f" % (wall.min() / ns, np.median(wall) / ns, wall.max() / ns))
+    print("   group  wall  work  sleep  rounds  lanes/round  noise-work  noise-sleep   (every 64th group in order of period)")
+    for g in list(range(0, a.shape[0], 64)) + [int(order[-1])]:
+        print("   %5d %5.0f %5.0f %6.0f %7.0f %12.1f %11.0f %12.0f" % (g, wall[g] / ns, a[g, 8] / ns, a[g, 14] / ns, a[g, 9], a[g, 10] / max(a[g, 9], 1), a[g, 11] / ns, a[g, 12] / ns))
 main()

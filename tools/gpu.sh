@@ -86,7 +86,7 @@ run_step() {
       done; done ;;
     diag)
       # phase breakdown of the wave-specialised kernels from the diagnostic build (`make diag`)
-      timeout -k 10 200 python tools/diag_ws.py | tee gpurun_out/diag_ws.txt ;;
+      timeout -k 10 200 python tools/diag_ws.py "$@" | tee gpurun_out/diag_ws.txt ;;
     full)
       # the round's evidence pass: tests, smoke, kernel trace, traffic and SQ counters (exact + fma), bench
       local tag=${1:-r03}

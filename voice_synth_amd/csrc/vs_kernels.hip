@@ -779,20 +779,21 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
     bool run = true;
     int kdone = 0; /* falling samples this lane has been through (lanes of a wave may differ in T2) */
     if (fast) {
-      /* whole trips of 8 (k0 + 8 <= T2); the flank falls monotonically, so a trip whose last
-       * sample is not below DC holds no break.  Stores are unconditional: slots at and behind
-       * the break are written again by the closed phase (2*T2 + 8 <= T). */
+      /* trips of 8, the last one possibly partial (the cos rows are padded to a multiple of 8); the
+       * flank falls monotonically, so a whole trip whose last sample is not below DC holds no break.
+       * Stores are unconditional: slots at and behind the break, and behind the flank, are written
+       * again by the closed phase (2*T2 + 8 <= T). */
       double cv[8];
-      if (PREFETCH && (8 <= T2)) {
+      if (PREFETCH) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) cv[k] = trow[k];
       }
-      for (int k0 = 0; __any(run && (k0 + 8 <= T2)); k0 += 8) {
-        if (run && (k0 + 8 <= T2)) {
-          kdone = k0 + 8;
+      for (int k0 = 0; __any(run && (k0 < T2)); k0 += 8) {
+        if (run && (k0 < T2)) {
+          kdone = k0 + 8; /* >= T2 behind the last trip: nothing is left for the general sequence below */
           double nv[8];
           if (PREFETCH) {
-            if (k0 + 16 <= T2) { /* next trip's cos values, read behind this trip's arithmetic */
+            if (k0 + 8 < T2) { /* next trip's cos values, read behind this trip's arithmetic */
 #pragma unroll
               for (int k = 0; k < 8; ++k) nv[k] = trow[k0 + 8 + k];
             }
@@ -808,13 +809,14 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
             for (int k = 0; k < 8; ++k) cv[k] = nv[k];
           }
           const VsRun8 r8 = vs_run8(ring, s.wpos, C, T2 + k0, lane);
-          if (__any(x[7] < c.thr)) {
+          if (__any((x[7] < c.thr) || (k0 + 8 > T2))) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-              const bool brk = run && (x[k] < c.thr); /* if(x[i] < par.DC) break; */
+              const bool in = k0 + k < T2;                   /* for(i = par.T2; i < 2*par.T2; i++) */
+              const bool brk = run && in && (x[k] < c.thr); /* if(x[i] < par.DC) break; */
               T3 = brk ? (T2 + k0 + k) : T3;
               run = run && !brk;
-              psum = run ? (psum + vs_sq_f(x[k])) : psum;
+              psum = (run && in) ? (psum + vs_sq_f(x[k])) : psum;
             }
             vs_run8_store_all(r8, x);
             asm volatile("; falling trip with the break");
@@ -827,7 +829,7 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         }
       }
     }
-    /* general sequence: everything when !fast, the last T2 mod 8 samples otherwise */
+    /* general sequence: everything when !fast, nothing otherwise */
     for (int k0 = kdone; run && (k0 < T2); k0 += 4) {
       double v[4];
       int xsv[4];
