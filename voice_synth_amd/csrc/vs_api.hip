@@ -534,6 +534,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   int ltab_entries = 0;
   size_t lds_bytes = 0;
   int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2;
+  bool all_deep = true; /* every group's ring holds 1.65 of its longest cycles or more (see the thresholds below) */
   if (!filter_only) {
     int rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min);
     if (rc != VS_OK) return rc;
@@ -550,6 +551,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       int tb = 1;
       for (size_t l = w0; l < n_lanes && l < w0 + G; l++) tb = std::max(tb, (int)dl[l].tbound);
       const double rho = (double)(slots - VS_SS) / (double)tb;
+      if (rho < 1.65) all_deep = false;
       int thr = 32;
       if (rho >= 1.65) thr = 64;
       else if (rho >= 1.45) thr = 58;
@@ -591,8 +593,12 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       size_t noisy = 0;
       for (size_t l = 0; l < n_lanes; l++) noisy += (dl[l].flags & VS_DF_NOISE) ? 1 : 0;
       /* only where there is noise to hand over: without it the third wavefront just relays
-       * progress words (BASELINE config 2's shape: 3.01 ms against 2.75 with two roles) */
-      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+       * progress words (BASELINE config 2's shape: 3.01 ms against 2.75 with two roles); and only over
+       * deep rings: the filter wavefront of the three-role kernel waits for ALL of its lanes, which a
+       * ring of barely one cycle cannot feed (BASELINE config 5's F0 sweep: 4.4 ms against 3.66 with two
+       * roles, profiles/r03_kernel_experiments.txt) */
+      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && all_deep && (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT)
+        ws_roles = 3;
       if (tune.ws_roles == 2) ws_roles = 2;
       if (tune.ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
       if (ws_roles == 3) ws_pair_bytes = bytes3;

@@ -25,7 +25,9 @@
 
 /* three-role kernel: order boxes per lane between the open-phase and the noise wavefront, and the
  * LDS words per lane of a group's progress bookkeeping (gpub, npub, oseq, otak, 3 words per box) */
+#ifndef VS_ORDER_DEPTH
 #define VS_ORDER_DEPTH 2
+#endif
 #define VS_SYNC_WORDS_3 (4 + 3 * VS_ORDER_DEPTH)
 
 #define VS_TRASH_ROWS 8 /* ring rows [C, C+8): where lanes that must not emit send their 8-sample trips */
