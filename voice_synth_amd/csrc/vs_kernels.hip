@@ -385,7 +385,7 @@ __device__ __forceinline__ void vs_wrap_select8(uint32_t A, uint32_t B, int kw, 
 template <int W>
 __device__ __forceinline__ void vs_lds_store16(uint32_t addr, int v)
 {
-  *(vs_lds_i16 *)(addr + (uint32_t)(W * VS_RING_STEP)) = (int16_t)v;
+  *(vs_lds_i16 *)(uintptr_t)(addr + (uint32_t)(W * VS_RING_STEP)) = (int16_t)v;
 }
 
 template <int W>
