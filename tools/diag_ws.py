@@ -9,8 +9,8 @@ from voice_synth_amd import configs
 GN = ["jitter+shimmer", "rising", "Knew+falling", "closed", "noise", "bookkeeping", "sleep/poll", "loop ctl"]
 FN = ["superstep+publish", "-", "-", "-", "-", "-", "sleep/poll", "poll+decide"]
 def main():
-    n = 65536
     cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     specs, fs, dur, label = configs.config_specs(cfg, n)
     print(label)
     lanes, d = vs.lanes_from_specs(specs); ns = vs.num_samples(fs, d)

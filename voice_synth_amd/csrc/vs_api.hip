@@ -541,11 +541,14 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     /* Super-step threshold, per 64-utterance group, from how many of the group's longest cycles
      * its ring holds (rho): a group whose ring holds barely one cycle cannot wait for all of its
      * lanes.  One-wave kernel: the table of vs_ring_policy (replayed period sequences).
-     * Wave-specialised kernel, measured (tools/gpu_sweep.sh, gpu_r2_probe4.sh, gpu_r2_ab4.sh): with
-     * a SIMD per wavefront the generator has slack, so the filter should not wait for stragglers
-     * (super-steps from 62 %); when generator and filter share a SIMD the filter is the
-     * bottleneck and only runs full super-steps if the ring is deep enough (rho >= 1.65: BASELINE
-     * config 3), three quarters otherwise (the long periods of config 5's F0 sweep). */
+     * Wave-specialised kernel, measured (profiles/README.md, r03_kernel_experiments.txt): over a deep
+     * ring (rho >= 1.65: BASELINE configs 3 and 4) the filter wavefront waits for ALL of its lanes --
+     * they then share one position, and the super-step loop runs without the copy of the window, the
+     * exec masks and the per-lane bounds that a wavefront of stragglers costs (config 4's shard, a SIMD
+     * per wavefront: 4.88 ms against 5.25 with super-steps from 62 %; in VS_ARITH_FMA, whose filter is
+     * no slower than the generator, 4.01 against 3.95 -- vs_launch lowers the threshold again there).
+     * Over shallower rings: three quarters of the lanes when generator and filter share a SIMD (the
+     * long periods of config 5's F0 sweep), 62 % when each has its own. */
     const bool ws_shared_simd = wave_specialised && grid > 2u * cus;
     for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
       int tb = 1;
@@ -556,7 +559,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       if (rho >= 1.65) thr = 64;
       else if (rho >= 1.45) thr = 58;
       else if (rho >= 1.33) thr = 48;
-      if (wave_specialised) thr = ws_shared_simd ? (rho >= 1.65 ? 64 : 48) : 40;
+      if (wave_specialised) thr = (rho >= 1.65) ? 64 : (ws_shared_simd ? 48 : 40);
       for (size_t l = w0; l < n_lanes && l < w0 + G; l++) dl[l].ready_min = thr;
     }
     ready_min = tune.ready_min > 0 ? tune.ready_min : 0; /* 0: the groups' own thresholds */
@@ -625,6 +628,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
+  p->ws_shared_simd = (wave_specialised && grid > 2u * cus) ? 1 : 0;
   p->group_lanes = group_lanes;
   p->ws_pair_bytes = ws_pair_bytes;
   p->filter_only = filter_only;
@@ -791,6 +795,9 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.ring_slots = p->ring_slots;
   a.ltab_entries = p->ltab_entries;
   a.ready_min = p->ready_min;
+  /* a SIMD per wavefront and fused multiply-adds: the filter is as quick as the generator and does
+   * better not to wait for the last lane (see the thresholds in vs_plan_create_impl) */
+  if (p->wave_specialised && !p->ws_shared_simd && p->ctx->arith == VS_ARITH_FMA && a.ready_min == 0) a.ready_min = 40;
   a.diag = p->d_diag;
   a.err = p->d_err;
   a.sink = p->d_sink;

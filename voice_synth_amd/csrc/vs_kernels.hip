@@ -1709,11 +1709,27 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
       const int n_live = __builtin_popcountll(__ballot(live));
       const int n_ready = __builtin_popcountll(__ballot(ready));
       if ((n_ready > 0) && (n_ready * 64 >= n_live * ready_min)) {
+        /* Every lane has its own n, so "all 24 samples lie inside the row" is a per-lane question -- but
+         * one that only a lane's LAST super-step answers with no (N is no multiple of 24), or every one
+         * when rows are not 4-byte aligned.  Asked once per super-step for the whole wavefront it leaves
+         * the common case without the 24 per-sample bounds tests and the exec masks around them. */
+        const bool inside = (args.vec_ok != 0) && (n + VS_SS <= N);
+        if (__all(!ready || inside)) {
+          if (ready) {
+            int outv[VS_SS];
+            vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
+            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                              n, N, true, outv, xpre);
+          }
+        } else {
+          if (ready) {
+            int outv[VS_SS];
+            vs_u32x4 xpre[VS_SS / 8];
+            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                           n, N, args.vec_ok != 0, outv, xpre);
+          }
+        }
         if (ready) {
-          int outv[VS_SS];
-          vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-          vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
-                                                         n, N, args.vec_ok != 0, outv, xpre);
           rslot += VS_SS;
           if (rslot >= C) rslot = 0;
           n += VS_SS;
