@@ -136,6 +136,26 @@ def test_longest_period_of_the_wide_ring_and_beyond(engine):
     assert e.value.code == vs._ffi.VS_ERR_UNSUPPORTED
 
 
+def test_which_fused_kernel_a_plan_takes(engine):
+    """the roles of the wave-specialised kernel are chosen by the shape of the work, not by what happens to
+    fit the LDS: three (open phase | noise | filter) on a full grid of deep rings with glottal noise
+    (BASELINE config 3), two where the rings hold barely a cycle (config 5's F0 sweep: a filter wavefront
+    that waits for all of its lanes starves there), where there is no glottal noise (config 2's shape),
+    and where every wavefront has a SIMD of its own (config 4's shard)."""
+    def kernel(cfg, n):
+        specs, fs, dur, _ = configs.config_specs(cfg, n)
+        lanes, d = vs.lanes_from_specs(specs)
+        plan = engine.plan(lanes, vs.num_samples(fs, d))
+        name = plan.kernel_name(vs.VS_KIND_SYNTH)
+        plan.close()
+        return name
+    assert kernel(3, 65536) == "vs_synth_ws_kernel<0, true, 3>"
+    assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(2, 65536) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 2>"   # a chunk of the delivery pipelines
+
+
 def test_mixed_batch_every_option_combination(engine):
     """one batch whose lanes differ in everything: rate, F0, options on/off, vowel, output noise"""
     specs = []
