@@ -550,13 +550,17 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
     for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
     /* words in front of the cycle's first noise draw (q0 + w < 0) go to the trash rows */
     char *A = (m > 0) ? run.A : trashA, *B = (m > 0) ? run.B : trashA;
+    uint32_t pw[8];
+    vs_wrap_select8(vs_lds_addr(A), vs_lds_addr(B), run.kw, pw);
+    const uint32_t trash32 = vs_lds_addr(trashA);
 #pragma unroll
-    for (int w = 0; w < 8; ++w) {
-      char *pw = (w < run.kw) ? A : B;
-      if (w < 3) pw = (q0 + w >= 0) ? pw : trashA;
-      if (TAIL) pw = (q0 + w < m) ? pw : trashA;
-      *(int16_t *)(pw + w * VS_RING_STEP) = (int16_t)xv[w];
+    for (int w = 0; w < 3; ++w) pw[w] = (q0 + w >= 0) ? pw[w] : trash32;
+    if (TAIL && __any(q0 + 8 > m)) { /* a cycle whose noise ends inside its first trip */
+#pragma unroll
+      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : trash32;
     }
+    vs_lds_store16<0>(pw[0], xv[0]); vs_lds_store16<1>(pw[1], xv[1]); vs_lds_store16<2>(pw[2], xv[2]); vs_lds_store16<3>(pw[3], xv[3]);
+    vs_lds_store16<4>(pw[4], xv[4]); vs_lds_store16<5>(pw[5], xv[5]); vs_lds_store16<6>(pw[6], xv[6]); vs_lds_store16<7>(pw[7], xv[7]);
     q0 += 8;
     b += 2u;
     vs_run8_advance(run, C);
@@ -648,7 +652,8 @@ template <bool LOG, bool PUB = false, bool SPLIT = false>
 __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t *ring, int C,
                                               int lane, int N, const double *ltab,
                                               vs_cycle_rec *logrow, int log_cap, VsDiag &dg,
-                                              int *gpub_lane = nullptr, const VsOrderBox ord = VsOrderBox())
+                                              int *gpub_lane = nullptr, const VsOrderBox ord = VsOrderBox(),
+                                              const VsRoundKeys *keys = nullptr)
 {
   VS_DIAG_ADD(dg, 7)
   const float Amplitude = s.amp_next;
@@ -921,9 +926,15 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
         vs_post_order(ord, lane, s, d0, T3, T, NDW);
         handed = true;
       } else {
-        VsRoundKeys rk;
-        vs_round_keys(c.key0, c.key1, rk);
-        vs_noise_trips<PUB, false>(ring, C, lane, rk, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
+        /* the lane's ten round keys: the caller's, made once per launch (the generator wavefront of the
+         * two-role kernel has the registers), or made here per cycle (the one-wave kernel has not) */
+        if (keys) {
+          vs_noise_trips<PUB, false>(ring, C, lane, *keys, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
+        } else {
+          VsRoundKeys rk;
+          vs_round_keys(c.key0, c.key1, rk);
+          vs_noise_trips<PUB, false>(ring, C, lane, rk, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
+        }
       }
     } else if (T4 == 0) {
       /* T4 == 0 on the general sequence: the draws map to i = T3 + q, q = 0..m-1 */
@@ -1441,6 +1452,8 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
   vs_load_cfg(g.L, c, s);
   vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
+  VsRoundKeys rk; /* two roles: this wavefront draws the noise itself (three: the noise wavefront has its own) */
+  if (!SPLIT) vs_round_keys(c.key0, c.key1, rk);
   int spins = 0;
   /* A poll that cannot end differently from the last one is cut short: whether a round starts depends
    * on this wavefront's own state (which only a round changes) and on two words per lane written by
@@ -1490,7 +1503,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
       if (SPLIT) {
         if (want) vs_cycle_emit<false, false, true>(c, s, g.ring, C, lane, N, g.ltab, nullptr, 0, dg, nullptr, g.ord);
       } else {
-        if (want) vs_cycle_emit<false, true, false>(c, s, g.ring, C, lane, N, g.ltab, nullptr, 0, dg, &g.gpub[lane]);
+        if (want) vs_cycle_emit<false, true, false>(c, s, g.ring, C, lane, N, g.ltab, nullptr, 0, dg, &g.gpub[lane], VsOrderBox(), &rk);
         VS_LDS_RELEASE();
         __hip_atomic_store(&g.gpub[lane], s.g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
