@@ -45,3 +45,32 @@ def test_full_batch_blended_pole_sets_every_sample(engine):
     bad, total = _compare(engine, lanes, ns)
     print("%s: %d of %d samples differ" % (label, bad, total))
     assert bad == 0
+
+
+@pytest.mark.parametrize("index,n,kernel", [(3, 65536, "vs_synth_ws_kernel<0, true, 3>"), (3, 65536 - 219, "vs_synth_ws_kernel<0, true, 3>"),
+                                            (5, 65536 - 219, "vs_synth_ws_kernel<0, true, 2>")])
+def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel):
+    """what bench.py times -- ONE launch of the plan of the whole batch (the tests above go through the
+    delivery pipeline, i.e. plans of 16384 utterances, which never take the full-grid kernels): the
+    three-role kernel on config 3, with a last group of 37 utterances and three empty groups behind it in
+    its workgroup (their stores go to the sink row), and the two-role kernel on the full grid of config 5"""
+    specs, fs, dur, label = configs.config_specs(index, n)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    plan = engine.plan(lanes, ns)
+    out = engine.dev_alloc(n * ns * 2)
+    try:
+        assert plan.kernel_name(vs.VS_KIND_SYNTH) == kernel
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        engine.synchronize()
+        assert plan.status() == 0
+        got = engine.dev_download(out, (n, ns), np.int16)
+    finally:
+        engine.dev_free(out)
+        plan.close()
+    bad = 0
+    for lo in range(0, n, 8192):
+        hi = min(n, lo + 8192)
+        bad += int((got[lo:hi] != po.synth([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
+    print("%s, one launch of %d utterances: %d of %d samples differ" % (label, n, bad, got.size))
+    assert bad == 0
