@@ -1142,14 +1142,18 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
                      "v"(xin[t + 6]), "v"(xin[t + 7]));
       }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-      double acc = (double)xin[t] * gain;
+      double acc;
       const double y1 = y[(t + VS_SS - 1) % VS_SS];
       if (ARITH == VS_ARITH_EXACT) {
         /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
-         * difference rounded on its own */
+         * difference rounded on its own.  x*gain itself is EXACT in double -- an int16 times a float
+         * gain has at most 16 + 24 significant bits -- so the first difference, x*gain - RN(A[1]*y[1]),
+         * is one fused multiply-add with the same single rounding: one instruction less per sample. */
+        acc = __builtin_fma((double)xin[t], gain, -(a[1] * y1));
 #pragma unroll
-        for (int j = 1; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
+        for (int j = 2; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
       } else {
+        acc = (double)xin[t] * gain;
         /* two partial sums over the older taps (a lone wavefront issues an independent fp64
          * instruction every ~5.3 ticks and a dependent one every ~8.4, so two alternating chains
          * never wait), the newest tap (j = 1) last: it is the only one on the sample-to-sample
