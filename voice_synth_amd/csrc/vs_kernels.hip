@@ -1388,10 +1388,11 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  *   two roles (generator | filter) -- grids that leave at least half of the chip's SIMDs empty
  *     (e.g. BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024
  *     SIMDs): one or two pairs per workgroup, every wavefront has a SIMD of its own and a launch
- *     takes max(generator, filter) instead of their sum (1.35-1.6x);
+ *     takes max(generator, filter) instead of their sum (1.35-1.6x); and full grids that do not suit
+ *     the third role (no glottal noise; rings of barely one cycle: vs_plan_create_impl);
  *
- *   three roles (open phase | noise | filter) -- full grids (BASELINE config 3: 1024 groups on 1024
- *     SIMDs): four groups per 768-thread workgroup, one workgroup per CU, wavefronts laid out
+ *   three roles (open phase | noise | filter) -- full grids over deep rings (BASELINE config 3: 1024
+ *     groups on 1024 SIMDs): four groups per 768-thread workgroup, one workgroup per CU, wavefronts laid out
  *     role-major so that every SIMD hosts the three wavefronts of ONE group (a workgroup's wavefronts
  *     are dealt to the CU's four SIMDs cyclically: w, w+4, w+8 share a SIMD).  Why three: a lone
  *     wavefront issues one instruction -- vector, scalar or LDS alike -- every ~5.25 cycles, and the
