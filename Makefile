@@ -16,6 +16,7 @@ CSRC    := $(PKG)/csrc
 LIBDIR  := $(PKG)/lib
 BINDIR  := $(PKG)/bin
 
+KERNEL_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_dev_primitives.h $(CSRC)/vs_dev_generator.h $(CSRC)/vs_dev_filter.h include/voice_synth.h
 HIPFLAGS := -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
 CFLAGS   := -O2 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Wno-unused-parameter
 
@@ -29,11 +30,11 @@ $(LIBDIR) $(BINDIR):
 $(CSRC)/vs_host.o: $(CSRC)/vs_host.c $(CSRC)/vs_tables.h include/voice_synth.h
 	$(CC) $(CFLAGS) -c -o $@ $<
 
-$(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+$(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 # the one-wave kernel once more with 16 utterances per wavefront: periods beyond the 64-column ring
-$(CSRC)/vs_kernels_narrow.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+$(CSRC)/vs_kernels_narrow.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DVS_GROUP_LANES=16 -c -o $@ $<
 
 $(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
@@ -68,7 +69,7 @@ clean:
 
 # diagnostic build with s_memtime stamps (never shipped, never timed): tools/diag_bench.py
 diag: $(LIBDIR)/libvoicesynth_diag.so
-$(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(CSRC)/vs_device.h include/voice_synth.h
+$(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
 $(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl

@@ -4,7 +4,7 @@
 
 (flowgen_shimmer.c:387, 398: an IEEE division, a product, a difference, ceil, a cast) and the
 addition to (short)DC behind it by ONE fused multiply-add and a truncating conversion whose low 16
-bits are the sample (vs_noise_sample() in voice_synth_amd/csrc/vs_kernels.hip; the proof is in its
+bits are the sample (vs_noise_sample() in voice_synth_amd/csrc/vs_dev_generator.h; the proof is in its
 comment).  That is only admissible if it is the SAME integer
 for every possible draw and every width the short sequence accepts (N <= 65534), so it is
 checked here on the CPU -- exhaustively over all 2^31 draws for a set of widths that includes

@@ -1,5 +1,5 @@
 """round2int() of vowel_new.c:413-427 against the form the filter super-step uses, ceil(x - 0.5): they
-differ exactly on the set the super-step tests for (vs_superstep in csrc/vs_kernels.hip: high word of a
+differ exactly on the set the super-step tests for (vs_superstep in csrc/vs_dev_filter.h: high word of a
 tiny negative value, or a low word of all ones), where it falls back to the literal form.  numpy float64
 arithmetic is IEEE, as the device's; the device repeats the comparison in vs_ctx_selftest() [3]."""
 import numpy as np

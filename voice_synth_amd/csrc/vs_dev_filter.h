@@ -1,0 +1,171 @@
+/*
+ * vs_dev_filter.h -- the filter: one super-step of 24 samples of vowel_new.c:266-289 per lane (vs_superstep)
+ * Included by vs_kernels.hip only (device code, one translation unit per build: the 64-column build and
+ * the narrow one, -DVS_GROUP_LANES=16).
+ */
+#ifndef VS_DEV_FILTER_H
+#define VS_DEV_FILTER_H
+
+/* the 8 samples of one granule / of 16 bytes of a PCM row, as integers */
+__device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
+{
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    x[2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
+    x[2 * e + 1] = (int)v[e] >> 16;
+  }
+}
+
+/*
+ * One filter super-step of one lane: 24 samples of vowel_new.c:266-289 starting at the lane's
+ * own position n.  x comes from the lane's ring column (rp = &ring[rslot][lane], never wraps
+ * inside a super-step because ring_slots is a multiple of VS_SS and rslot advances by VS_SS
+ * from 0) or, for VS_KIND_FILTER, from HBM.  The 24 int16 results leave as three
+ * 16-byte stores (store_ok: lanes beyond the batch run along in the all-lanes loop of the
+ * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
+ * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
+ */
+template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1>
+__device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
+                                             double gain, double pre, const int16_t *rp,
+                                             const int16_t *__restrict__ irow,
+                                             int16_t *__restrict__ orow, int n, int N, bool vec_ok,
+                                             int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8],
+                                             bool store_ok = true)
+{
+  /* WHOLE: the caller has taken this decision out of its loop (1: 16-byte stores, 0: sample by sample).
+   * With it -- and store_ok a constant -- nothing branches between the ring reads and their use. */
+  const bool whole = (WHOLE < 0) ? (vec_ok && (n + VS_SS <= N)) : (WHOLE != 0);
+  int xin[VS_SS];
+  if (KIND == VS_KIND_FILTER) {
+    if (whole) {
+      /* xnext[] holds this super-step's 48 bytes, loaded one super-step ago; the loads for the
+       * next one are issued now and complete behind the ~1300 instructions below (with one
+       * wave per SIMD nothing else hides an HBM round trip) */
+#pragma unroll
+      for (int k = 0; k < VS_SS / 8; ++k) vs_unpack8(xnext[k], &xin[8 * k]);
+      if (n + 2 * VS_SS <= N) {
+#pragma unroll
+        for (int k = 0; k < VS_SS / 8; ++k) xnext[k] = *(const vs_u32x4 *)(irow + n + VS_SS + 8 * k);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
+    }
+  } else {
+    /* the first 8 now, the rest in two more batches issued from inside the sample loop (each a
+     * chunk ahead of its use): 24 ring samples held at once are 16 registers too many */
+#pragma unroll
+    for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
+  }
+
+  /* results leave in chunks of 8 samples = one 16-byte store, as soon as a chunk is complete: 24
+   * pending results would cost 24 registers (the three-role kernel runs at 168 per wavefront) */
+  auto put8 = [&](int k) {
+    if (whole) {
+      vs_u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = PACKED ? vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1])
+                      : vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+      if (store_ok) *(vs_u32x4 *)(orow + n + 8 * k) = v;
+    } else {
+#pragma unroll
+      for (int t = 8 * k; t < 8 * k + 8; ++t) {
+        int v = outv[t];
+        if (PACKED) v = (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
+        if (store_ok && (n + t < N)) orow[n + t] = (int16_t)v;
+      }
+    }
+  };
+
+  if (KIND == VS_KIND_SOURCE) {
+#pragma unroll
+    for (int t = 8; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t]; /* the flow itself */
+#pragma unroll
+    for (int k = 0; k < VS_SS / 8; ++k) put8(k);
+  } else {
+    const double ym1 = y[VS_SS - 1]; /* y[n-1]: only the quirk path below needs it once y[23] is replaced */
+    int qhi = 0x7FFFFFFF;            /* signed minimum of the high words of the rounded values */
+    uint32_t qlo = 0u;               /* unsigned maximum of their low words */
+#pragma unroll
+    for (int t = 0; t < VS_SS; ++t) {
+      if (KIND != VS_KIND_FILTER && (t & 7) == 0) {
+        if (t + 8 < VS_SS) {
+#pragma unroll
+          for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
+        }
+        /* this chunk's eight samples are all "used" here: ONE s_waitcnt for the batch (the LDS answers in
+         * order) instead of one in front of every sample's first use -- to a wavefront that issues an
+         * instruction every ~5.3 ticks whatever it is, a wait that has nothing to wait for costs as much
+         * as a multiplication (tools/ubench/ubench5.hip) */
+        asm volatile("" ::"v"(xin[t]), "v"(xin[t + 1]), "v"(xin[t + 2]), "v"(xin[t + 3]), "v"(xin[t + 4]), "v"(xin[t + 5]),
+                     "v"(xin[t + 6]), "v"(xin[t + 7]));
+      }
+      /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
+      double acc;
+      const double y1 = y[(t + VS_SS - 1) % VS_SS];
+      if (ARITH == VS_ARITH_EXACT) {
+        /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
+         * difference rounded on its own.  x*gain itself is EXACT in double -- an int16 times a float
+         * gain has at most 16 + 24 significant bits -- so the first difference, x*gain - RN(A[1]*y[1]),
+         * is one fused multiply-add with the same single rounding: one instruction less per sample. */
+        acc = __builtin_fma((double)xin[t], gain, -(a[1] * y1));
+#pragma unroll
+        for (int j = 2; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
+      } else {
+        acc = (double)xin[t] * gain;
+        /* two partial sums over the older taps (a lone wavefront issues an independent fp64
+         * instruction every ~5.3 ticks and a dependent one every ~8.4, so two alternating chains
+         * never wait), the newest tap (j = 1) last: it is the only one on the sample-to-sample
+         * critical path */
+        double p0 = acc, p1 = -(a[2] * y[(t + VS_SS - 2) % VS_SS]);
+#pragma unroll
+        for (int j = 3; j <= VS_ORDER; ++j) {
+          const double yj = y[(t + VS_SS - j) % VS_SS];
+          if (j & 1) p0 = __builtin_fma(-a[j], yj, p0);
+          else p1 = __builtin_fma(-a[j], yj, p1);
+        }
+        acc = __builtin_fma(-a[1], y1, p0 + p1);
+      }
+      /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284.  PRE1: every
+       * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
+      const double o = PRE1 ? (acc - y1)
+                            : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
+      /* PACKED: the caller does not look at outv[]; the clamp rides on the packing (put8) */
+      outv[t] = PACKED ? vs_round2int_half_down_unclamped(o) : vs_round2int_half_down(o);
+      /* rounded HERE: left to itself the compiler keeps all 24 arguments (48 registers) and rounds
+       * them behind the quirk test below, where the other branch does not need the results */
+      asm volatile("" : "+v"(outv[t]));
+      {
+        const int ohi = __double2hiint(o);
+        const uint32_t olo = (uint32_t)__double2loint(o);
+        qhi = (ohi < qhi) ? ohi : qhi;
+        qlo = (olo > qlo) ? olo : qlo;
+      }
+      y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+      if ((t & 7) == 7) put8(t >> 3);
+      /* keep each sample's products next to its chain: hoisted across samples they only park
+       * in the accumulator registers and come back, two moves each way */
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu))) {
+      /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
+       * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again,
+       * literally, and store it again */
+#pragma unroll
+      for (int t = 0; t < VS_SS; ++t) {
+        const double y1 = (t == 0) ? ym1 : y[t - 1];
+        const double o = PRE1 ? (y[t] - y1)
+                              : ((ARITH == VS_ARITH_EXACT) ? (y[t] - pre * y1) : __builtin_fma(-pre, y1, y[t]));
+        outv[t] = vs_round2int(o);
+      }
+#pragma unroll
+      for (int k = 0; k < VS_SS / 8; ++k) put8(k);
+    }
+  }
+}
+
+#endif

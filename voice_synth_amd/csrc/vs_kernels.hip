@@ -43,1167 +43,10 @@
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
 
-#define VS_PHILOX_M0 0xD2511F53u
-#define VS_PHILOX_M1 0xCD9E8D57u
-#define VS_PHILOX_W0 0x9E3779B9u
-#define VS_PHILOX_W1 0xBB67AE85u
+#include "vs_dev_primitives.h"
+#include "vs_dev_generator.h"
+#include "vs_dev_filter.h"
 
-typedef uint32_t vs_u32x4 __attribute__((ext_vector_type(4), aligned(4)));   /* 16 bytes of a PCM row: rows are only 4-byte aligned */
-
-/* Diagnostic build only (-DVS_DIAG, tools/diag_bench.py): s_memtime stamps at phase boundaries,
- * summed per wavefront into args.diag.  The shipped library is built without it. */
-struct VsDiag {
-  unsigned long long acc[8];
-  unsigned long long t;
-  unsigned long long rounds, attend; /* generator rounds and the lanes that took part in them */
-};
-#ifdef VS_DIAG
-__device__ __forceinline__ unsigned long long vs_stamp()
-{
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define VS_DIAG_ADD(dg, k)                     \
-  {                                            \
-    const unsigned long long tn_ = vs_stamp(); \
-    (dg).acc[k] += tn_ - (dg).t;               \
-    (dg).t = tn_;                              \
-  }
-#else
-#define VS_DIAG_ADD(dg, k)
-#endif
-
-/* {lo & 0xFFFF, hi << 16} in one instruction (V_PERM_B32: bytes 0,1 of lo, then bytes 0,1 of hi) */
-__device__ __forceinline__ uint32_t vs_pack16(int lo, int hi)
-{
-  return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
-}
-
-/* a ^ b ^ c in one instruction (gfx950 V_BITOP3_B32, truth table 0x96) */
-__device__ __forceinline__ uint32_t vs_xor3(uint32_t a, uint32_t b, uint32_t c)
-{
-  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-}
-
-/* Philox4x32-10 (Salmon et al., SC'11), counter = (blk, 0, 0, 0). */
-__device__ __forceinline__ void vs_philox(uint32_t blk, uint32_t k0, uint32_t k1, uint32_t &o0,
-                                          uint32_t &o1, uint32_t &o2, uint32_t &o3)
-{
-  uint32_t c0 = blk, c1 = 0u, c2 = 0u, c3 = 0u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)VS_PHILOX_M0 * c0;
-    const uint64_t p1 = (uint64_t)VS_PHILOX_M1 * c2;
-    const uint32_t n0 = vs_xor3((uint32_t)(p1 >> 32), c1, k0);
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = vs_xor3((uint32_t)(p0 >> 32), c3, k1);
-    const uint32_t n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += VS_PHILOX_W0;
-    k1 += VS_PHILOX_W1;
-  }
-  o0 = c0; o1 = c1; o2 = c2; o3 = c3;
-}
-
-/* The ten round keys of a lane, made once per glottal cycle for the noise loop (the key
- * schedule k + r*W does not depend on the counter). */
-struct VsRoundKeys {
-  uint32_t a[10], b[10];
-};
-__device__ __forceinline__ void vs_round_keys(uint32_t k0, uint32_t k1, VsRoundKeys &rk)
-{
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    rk.a[r] = k0 + (uint32_t)r * VS_PHILOX_W0;
-    rk.b[r] = k1 + (uint32_t)r * VS_PHILOX_W1;
-    /* keep them as values: rematerialising the additions inside the loop is what this avoids */
-    asm volatile("" : "+v"(rk.a[r]), "+v"(rk.b[r]));
-  }
-}
-/* two consecutive blocks (blk, blk + 1) with the prepared keys: 8 draws, chains interleaved */
-__device__ __forceinline__ void vs_philox2(uint32_t blk, const VsRoundKeys &rk, uint32_t (&o)[8])
-{
-  uint32_t c0 = blk, c1 = 0u, c2 = 0u, c3 = 0u;
-  uint32_t e0 = blk + 1u, e1 = 0u, e2 = 0u, e3 = 0u;
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)VS_PHILOX_M0 * c0;
-    const uint64_t p1 = (uint64_t)VS_PHILOX_M1 * c2;
-    const uint64_t s0 = (uint64_t)VS_PHILOX_M0 * e0;
-    const uint64_t s1 = (uint64_t)VS_PHILOX_M1 * e2;
-    const uint32_t n0 = vs_xor3((uint32_t)(p1 >> 32), c1, rk.a[r]);
-    const uint32_t n2 = vs_xor3((uint32_t)(p0 >> 32), c3, rk.b[r]);
-    const uint32_t m0 = vs_xor3((uint32_t)(s1 >> 32), e1, rk.a[r]);
-    const uint32_t m2 = vs_xor3((uint32_t)(s0 >> 32), e3, rk.b[r]);
-    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
-    e1 = (uint32_t)s1; e3 = (uint32_t)s0; e0 = m0; e2 = m2;
-  }
-  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-  o[4] = e0; o[5] = e1; o[6] = e2; o[7] = e3;
-}
-
-/* per-lane constants of the generator */
-struct VsCfg {
-  float jitter, shimmer, K, Kvar, DC, noise, t_hi, t_lo, a_hi, a_lo;
-  int amp, P, T2, tab_off, dcs, thr;
-  uint32_t flags, key0, key1;
-};
-
-/* per-lane generator state: the complete carried state of flowgen_shimmer.c's loop
- * (DeltaPer[0], DeltaShimmer[0], T4, T, CountSamples) plus the draw counter */
-struct VsGen {
-  uint32_t d;
-  float dp0, ds0;
-  int T4, T, g, wpos, cyc;
-  /* the next cycle's period / amplitude / closing speed once its jitter, shimmer and Knew draws
-   * are made (vs_cycle_scalars) and before its samples are written (vs_cycle_emit) */
-  float amp_next, S_next, K_next;
-  bool pend;
-  int posted; /* three-role kernel: orders this lane has handed to the noise wavefront */
-};
-
-/* the Philox block the scalar draws of one cycle come from (local to vs_cycle_scalars) */
-struct VsBlk {
-  uint32_t idx, b0, b1, b2, b3;
-};
-
-/* next draw of the lane's sequential stream = what random() returns in the shimmed reference.
- * Called under the EXEC mask of the lanes that draw. */
-__device__ __forceinline__ uint32_t vs_draw(const VsCfg &c, VsGen &s, VsBlk &k)
-{
-  const uint32_t b = s.d >> 2;
-  if (b != k.idx) {
-    vs_philox(b, c.key0, c.key1, k.b0, k.b1, k.b2, k.b3);
-    k.idx = b;
-  }
-  /* word (d & 3) of the cached block; written as 64-bit select + shift so that the compiler
-   * does not turn a four-way select into an indexed scratch array */
-  const uint64_t q0 = (uint64_t)k.b0 | ((uint64_t)k.b1 << 32);
-  const uint64_t q1 = (uint64_t)k.b2 | ((uint64_t)k.b3 << 32);
-  const uint64_t q = (s.d & 2u) ? q1 : q0;
-  const uint32_t v = (uint32_t)(q >> ((s.d & 1u) * 32u));
-  s.d += 1u;
-  return v >> 1;
-}
-
-/* (1.0*random())/RAND_MAX of flowgen_shimmer.c:325,387,398 for a draw r in [0, 2^31): the
- * correctly rounded quotient r / 2147483647 from one multiply and two fused multiply-adds
- * (Markstein's final-step form: q0 = r*inv is within one ulp, the residual r - q0*d is exact,
- * inv = RN(1/d)).  Equality with IEEE division is verified EXHAUSTIVELY over all 2^31 draws,
- * on the CPU by tests/test_div_shortcut.py and on the device by vs_ctx_selftest(). */
-__device__ __forceinline__ double vs_unit_of_draw(uint32_t r)
-{
-  const double d = 2147483647.0;
-  const double inv = 0x1.00000002p-31;
-  const double x = (double)r;
-  const double q0 = x * inv;
-  const double e = __builtin_fma(-q0, d, x);
-  return __builtin_fma(e, inv, q0);
-}
-
-/* (signed short) of a double, as gcc/x86-64 converts it: through int32, low 16 bits */
-__device__ __forceinline__ int vs_short_of(double v) { return (int)(int16_t)(int)v; }
-
-/* round2int() of vowel_new.c:413-427:
- *     dec = x - floor(x); if (dec > 0.5) x = x + 1; clamp x to [-32767, 32767]; return floor(x)
- * dec comes from V_FRACT_F64: x - floor(x) is exact for every double except -1 < x < 0, where both
- * forms round x + 1 to nearest; the instruction only differs in returning the largest double
- * below 1 where the subtraction rounds up to 1.0 (tiny negative x), and both are > 0.5 there.
- * The "+1" stays a double addition (it is part of the reference's rounding sequence: the
- * reference returns 1 for x = -1e-20); the clamp moves behind the floor into integers, which
- * gives the same result for every finite x: floor is monotone, floor(+-32767) = +-32767, and
- * v_cvt_i32_f64 saturates beyond int32.  x is never NaN (stable filter, int16 input). */
-__device__ __forceinline__ int vs_round2int(double x)
-{
-  const double dec = __builtin_amdgcn_fract(x);
-  x = x + ((dec > 0.5) ? 1.0 : 0.0); /* x + 0.0 only turns -0.0 into +0.0; both floor to 0 */
-  const int v = (int)floor(x);
-  return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
-}
-
-/*
- * round2int() without its double rounding: ceil(x - 0.5), clamped.  This is round2int(x) for every
- * double x EXCEPT the ones for which the reference's "x = x + 1" rounds up to an integer although
- * x lies just below it -- the quirk set
- *     Q1 = [-2^-54, -0)                    (x + 1 rounds to 1.0: the reference returns 1, not 0)
- *     Q2 = { 2^m - 2^(m-53), m = 0..51 }   (mantissa all ones: x + 1 is a tie that rounds up)
- * (for |x| >= 1 both x - 0.5 and x + 1 are exact or round without reaching an integer; the interval
- * (-1, 1) is gone through case by case in tests/test_round2int.py and on the device by
- * vs_ctx_selftest [3]).  Every member of Q1 has a high word in [0x80000000, 0xBC900000] and every
- * member of Q2 a low word of 0xFFFFFFFF, so a super-step keeps the signed minimum of the high words
- * and the unsigned maximum of the low words of its 24 arguments (one V_MIN3 / V_MAX3 per two
- * samples) and, when either hits, rounds that super-step again with vs_round2int() -- outputs are
- * not fed back, so nothing else has to be redone.  Three fp64 instructions per sample instead of five.
- */
-__device__ __forceinline__ int vs_round2int_half_down_unclamped(double x) { return (int)ceil(x - 0.5); }
-__device__ __forceinline__ int vs_round2int_half_down(double x)
-{
-  const int v = vs_round2int_half_down_unclamped(x);
-  return (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
-}
-/* two rounded values, clamped to [-32767, 32767] and packed: V_CVT_PK_I16_I32 saturates to int16,
- * V_PK_MAX_I16 lifts -32768 to the reference's -32767 (vowel_new.c:423-424) -- two instructions for two
- * samples instead of two V_MED3_I32 and a V_PERM_B32 */
-typedef short vs_i16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t vs_clamp_pack16(int lo, int hi)
-{
-  const vs_i16x2 p = __builtin_amdgcn_cvt_pk_i16(lo, hi);
-  const vs_i16x2 floor_ = {(short)-32767, (short)-32767};
-  const vs_i16x2 q = __builtin_elementwise_max(p, floor_);
-  return __builtin_bit_cast(uint32_t, q);
-}
-#define VS_R2I_Q1_HI ((int)0xBC900000) /* high word of -2^-54, as a signed integer */
-
-/* (int)sqrt(v) of the reference (flowgen_shimmer.c:382) for a float-valued v >= 0: the
- * device sqrt only seeds an exact integer search, so its last-bit rounding cannot matter */
-__device__ __forceinline__ int vs_isqrt_floor(double v)
-{
-  int s = (int)sqrt(v);
-  if (s < 0) s = 0;
-  while ((double)(s + 1) * (double)(s + 1) <= v) ++s;
-  while (s > 0 && (double)s * (double)s > v) --s;
-  return s;
-}
-
-/*
- * LDS ring layout: int16 ring[C + 8][64] -- slot-major, lane l owns column l, one slot of all 64
- * lanes is 128 contiguous bytes, so a ds_write_b16 / ds_read_i16 of a wavefront touches every bank
- * once (two lanes per 4-byte bank, same dword).  Slots [C, C + 8) are the trash rows: where lanes that
- * must not emit send their 8-sample trips.  (A lane-major layout -- 16 contiguous bytes per lane and
- * 8 slots -- lets the filter side read 8 samples per LDS instruction, but single-sample writes then
- * hit every bank eight times over and the generator alone runs 15 % longer; measured in round 3,
- * profiles/r03_kernel_experiments.txt.)
- */
-/* utterances per group = lanes that own a ring column.  64, a whole wavefront -- except in the second
- * build of this file (vs_kernels_narrow.o, -DVS_GROUP_LANES=16), which exists for periods too long for a
- * 64-column ring (e.g. 48 kHz at F0 = 50 Hz with jitter: 1152 samples): a quarter of the columns, four
- * times the slots in the same LDS, three quarters of the wavefront idle.  Slow, and only ever used for
- * plans the wide ring cannot take (vs_plan_create); the reference accepts such rates
- * (flowgen_shimmer.c:535-540) and sizes its buffer by the period (fg:569). */
-#ifndef VS_GROUP_LANES
-#define VS_GROUP_LANES VS_WAVE
-#else
-#define vs_synth_kernel vs_synth_kernel_narrow /* the two builds end up in one library: no shared kernel names */
-#endif
-#define VS_RING_STEP (VS_GROUP_LANES * 2) /* bytes from a lane's slot s to its slot s + 1 */
-
-/* int16 index of ring slot `slot` (0 <= slot < C + 8; slots [C, C + 8) are the trash rows) */
-__device__ __forceinline__ int vs_ring_idx(int slot, int lane) { return slot * VS_GROUP_LANES + lane; }
-
-/* int16 index of sample i of the cycle being written: the cycle starts at slot wpos and wraps
- * at most once (wpos < C, i < C + VS_TRASH_ROWS). */
-__device__ __forceinline__ int vs_ring_at(int wpos, int C, int i, int lane)
-{
-  /* slot = (wpos + i) mod C for wpos + i < 2C, as min(s, s - C) on unsigned (two instructions) */
-  const unsigned sl = (unsigned)(wpos + i);
-  const unsigned wr = sl - (unsigned)C;
-  return vs_ring_idx((int)((sl < wr) ? sl : wr), lane);
-}
-
-/* Eight consecutive ring slots of a lane that start ANYWHERE (the noise trips follow the Philox
- * blocks, not the ring): the run wraps at most once, after kw slots.  A sample costs one compare,
- * one select and the store (the slot offset W*128 sits in the store's immediate). */
-typedef __attribute__((address_space(3))) char vs_lds_char;
-typedef __attribute__((address_space(3))) int16_t vs_lds_i16;
-struct VsRun8 {
-  char *A, *B; /* LDS address of slot 0 of the run before / after the wrap */
-  int kw;      /* slots before the wrap (>= 8: none in this run) */
-};
-__device__ __forceinline__ VsRun8 vs_run8(int16_t *ring, int wpos, int C, int i0, int lane)
-{
-  const unsigned sl = (unsigned)(wpos + i0);
-  const unsigned wr = sl - (unsigned)C;
-  const unsigned a0 = (sl < wr) ? sl : wr;
-  VsRun8 r;
-  r.kw = C - (int)a0;
-  r.A = (char *)ring + (a0 * (unsigned)VS_RING_STEP + (unsigned)(2 * lane));
-  r.B = r.A - (unsigned)C * (unsigned)VS_RING_STEP;
-  return r;
-}
-/* the run of the next 8 slots */
-__device__ __forceinline__ void vs_run8_advance(VsRun8 &r, int C)
-{
-  r.kw -= 8;
-  r.A += 8 * VS_RING_STEP;
-  const bool wrapped = r.kw <= 0; /* the whole of the next run lies behind the wrap */
-  r.A = wrapped ? r.B + 8 * VS_RING_STEP : r.A;
-  r.kw = wrapped ? r.kw + C : r.kw;
-  r.B = r.A - (unsigned)C * (unsigned)VS_RING_STEP;
-}
-/* all eight stores of a lane go to the trash rows [C, C + 8) */
-__device__ __forceinline__ VsRun8 vs_run8_trash(int16_t *ring, int C, int lane)
-{
-  VsRun8 r;
-  r.kw = 8;
-  r.A = (char *)ring + ((unsigned)C * (unsigned)VS_RING_STEP + (unsigned)(2 * lane));
-  r.B = r.A;
-  return r;
-}
-/* a lane's run if it still emits, the trash rows otherwise (field by field: a select of whole
- * structs makes the compiler index them in scratch memory) */
-__device__ __forceinline__ VsRun8 vs_run8_or_trash(bool emit, int16_t *ring, int wpos, int C, int i0, int lane)
-{
-  const VsRun8 a = vs_run8(ring, wpos, C, i0, lane);
-  const VsRun8 t = vs_run8_trash(ring, C, lane);
-  VsRun8 r;
-  r.kw = emit ? a.kw : t.kw;
-  r.A = emit ? a.A : t.A;
-  r.B = emit ? a.B : t.B;
-  return r;
-}
-
-/* The eight store addresses of a run: pw[w] = (w < kw) ? A : B as LDS byte addresses.  Written out as
- * eight compares into eight SGPR pairs and then eight selects: on gfx950 a VALU instruction must not read
- * a mask within two wait states of the VALU instruction that wrote it, and left to itself the compiler
- * pairs every compare with its select and puts an s_nop between them -- eight instructions per trip that
- * do nothing, each at the price of one that does (ubench5). */
-__device__ __forceinline__ uint32_t vs_lds_addr(const char *p) { return (uint32_t)(uintptr_t)(const vs_lds_char *)p; }
-__device__ __forceinline__ void vs_wrap_select8(uint32_t A, uint32_t B, int kw, uint32_t (&pw)[8])
-{
-  unsigned long long m0, m1, m2, m3, m4, m5, m6, m7;
-  asm volatile("v_cmp_lt_i32_e64 %8, 0, %18\n\t"
-               "v_cmp_lt_i32_e64 %9, 1, %18\n\t"
-               "v_cmp_lt_i32_e64 %10, 2, %18\n\t"
-               "v_cmp_lt_i32_e64 %11, 3, %18\n\t"
-               "v_cmp_lt_i32_e64 %12, 4, %18\n\t"
-               "v_cmp_lt_i32_e64 %13, 5, %18\n\t"
-               "v_cmp_lt_i32_e64 %14, 6, %18\n\t"
-               "v_cmp_lt_i32_e64 %15, 7, %18\n\t"
-               "v_cndmask_b32_e64 %0, %17, %16, %8\n\t"
-               "v_cndmask_b32_e64 %1, %17, %16, %9\n\t"
-               "v_cndmask_b32_e64 %2, %17, %16, %10\n\t"
-               "v_cndmask_b32_e64 %3, %17, %16, %11\n\t"
-               "v_cndmask_b32_e64 %4, %17, %16, %12\n\t"
-               "v_cndmask_b32_e64 %5, %17, %16, %13\n\t"
-               "v_cndmask_b32_e64 %6, %17, %16, %14\n\t"
-               "v_cndmask_b32_e64 %7, %17, %16, %15"
-               : "=&v"(pw[0]), "=&v"(pw[1]), "=&v"(pw[2]), "=&v"(pw[3]), "=&v"(pw[4]), "=&v"(pw[5]), "=&v"(pw[6]), "=&v"(pw[7]),
-                 "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3), "=&s"(m4), "=&s"(m5), "=&s"(m6), "=&s"(m7)
-               : "v"(A), "v"(B), "v"(kw));
-}
-template <int W>
-__device__ __forceinline__ void vs_lds_store16(uint32_t addr, int v)
-{
-  *(vs_lds_i16 *)(uintptr_t)(addr + (uint32_t)(W * VS_RING_STEP)) = (int16_t)v;
-}
-
-template <int W>
-__device__ __forceinline__ void vs_run8_store(const VsRun8 &r, int v)
-{
-  char *p = (W < r.kw) ? r.A : r.B;
-  *(int16_t *)(p + W * VS_RING_STEP) = (int16_t)v;
-}
-/* the same, but to the trash rows (address trashA of row C) unless ok */
-template <int W>
-__device__ __forceinline__ void vs_run8_store_if(const VsRun8 &r, char *trashA, bool ok, int v)
-{
-  char *p = (W < r.kw) ? r.A : r.B;
-  p = ok ? p : trashA;
-  *(int16_t *)(p + W * VS_RING_STEP) = (int16_t)v;
-}
-__device__ __forceinline__ void vs_run8_store_all(const VsRun8 &r, const int (&x)[8])
-{
-  uint32_t pw[8];
-  vs_wrap_select8(vs_lds_addr(r.A), vs_lds_addr(r.B), r.kw, pw);
-  vs_lds_store16<0>(pw[0], x[0]); vs_lds_store16<1>(pw[1], x[1]); vs_lds_store16<2>(pw[2], x[2]); vs_lds_store16<3>(pw[3], x[3]);
-  vs_lds_store16<4>(pw[4], x[4]); vs_lds_store16<5>(pw[5], x[5]); vs_lds_store16<6>(pw[6], x[6]); vs_lds_store16<7>(pw[7], x[7]);
-}
-
-/*
- * One glottal cycle of a lane is produced in two halves, vs_cycle_scalars() and vs_cycle_emit().
- */
-/* First half of a cycle: every draw of the cycle except the noise -- the jitter and shimmer
- * recursions with their rejection loops (flowgen_shimmer.c:248-313) and the closing-speed draw
- * (fg:325; the rising half-pulse between them consumes no draws, so the draw index is the same).
- * They fix the cycle's period T, amplitude and Knew -- no ring space is needed yet, so a lane
- * runs them as soon as its previous cycle is written, and the room check for the samples can
- * use the ACTUAL period instead of the worst case 1.2*P.  The Philox block the draws come from
- * lives only inside this function. */
-__device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDiag &dg)
-{
-  VS_DIAG_ADD(dg, 7)
-  VsBlk blk;
-  blk.idx = 0xFFFFFFFFu; blk.b0 = blk.b1 = blk.b2 = blk.b3 = 0u;
-  /* ---- jitter: fg:248-291 ---- */
-  if (c.flags & VS_DF_JITTER) {
-    const float dp1 = s.dp0; /* DeltaPer[1] = DeltaPer[0] */
-    for (;;) {
-      const uint32_t r = vs_draw(c, s, blk);
-      const float J = (float)(((double)r / (2147483647 * 10000.0)) * 40000.0 * (double)c.jitter -
-                              2.0 * (double)c.jitter);
-      const double Jd = (double)J;
-      s.dp0 = (float)((double)dp1 * (2.0 + Jd) / (2.0 - Jd) + 2.0 * (double)c.P * Jd / (2.0 - Jd));
-      s.T = vs_short_of(ceil((double)((float)c.P + s.dp0)));
-      if (!(((float)s.T > c.t_hi) || ((float)s.T < c.t_lo))) break;
-    }
-  }
-
-  /* ---- shimmer: fg:293-313 ---- */
-  float Amplitude = (float)c.amp;
-  float S = 0.0f;
-  if (c.flags & VS_DF_SHIMMER) {
-    const float ds1 = s.ds0;
-    for (;;) {
-      const uint32_t r = vs_draw(c, s, blk);
-      const float epsilon = (float)r / 2147483648.0f; /* (float)RAND_MAX == 2^31 */
-      S = (float)((double)epsilon * 4.0 * (double)c.shimmer - 2.0 * (double)c.shimmer);
-      const double Sd = (double)S;
-      s.ds0 = (float)((double)ds1 * (2.0 + Sd) / (2.0 - Sd) + 2.0 * (double)c.amp * Sd / (2.0 - Sd));
-      Amplitude = (float)c.amp + s.ds0;
-      if (!((Amplitude > c.a_hi) || (Amplitude < c.a_lo))) break;
-    }
-  }
-  /* ---- closing speed: fg:325 (one draw per cycle, always) ---- */
-  {
-    const uint32_t r = vs_draw(c, s, blk);
-    s.K_next = (float)((double)c.K * (1.0 + (double)(2.0f * c.Kvar) * (vs_unit_of_draw(r) - 0.5)));
-  }
-  s.amp_next = Amplitude;
-  s.S_next = S;
-  s.pend = true;
-  VS_DIAG_ADD(dg, 0)
-}
-
-/* psum + (float)x*(float)x of flowgen_shimmer.c:376 for an integer sample |x| <= 32767: the
- * square is exact in 32-bit integers and its conversion rounds exactly as the float product. */
-__device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
-
-/* Publishing progress through LDS: the LDS performs the operations of ONE wavefront in the order
- * they were issued, so a progress word stored after the data is seen after the data by whoever
- * reads the word first and the data second -- no wait for the data stores to come back is needed,
- * only the compiler must not move the accesses across each other (a fence with workgroup scope
- * would add an s_waitcnt lgkmcnt(0), a full LDS round trip, to every noise trip). */
-#define VS_LDS_RELEASE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
-
-#ifndef VS_PUB_EVERY
-#define VS_PUB_EVERY 1 /* wave-specialised kernel: the generator publishes its noise progress every N-th trip (power of two) */
-#endif
-
-/* Largest noise width the short noise sequence takes (see vs_noise_fast()). */
-#define VS_NDW_FAST 65534
-
-/*
- * One noise sample of the closed phase (flowgen_shimmer.c:387-389, 398-400):
- *     w    = (signed short)ceil(((1.0*random())/RAND_MAX)*NoiseDistWidth - NoiseDistWidth/2.)
- *     x[i] = truncate((float)x[i] + w)            with x[i] = (short)par.DC on [T3, T)
- * for a draw r in [0, 2^31), a width N <= VS_NDW_FAST and |(short)DC| + N/2 + 2 <= 32767 (no clamp,
- * no wrap), as the LOW 16 BITS of
- *     trunc(fma(r, N*inv, I - N/2 + 1 - 1e-10)),      I = (short)DC + 65536,  inv = 0x1.00000002p-31
- * -- one conversion, one fused multiply-add, one conversion, and the store takes the low half.
- * Why this is the reference's value for every r: with M = 2^31 - 1 (a prime) the exact quantity
- * V = r*N/M - N/2 is an integer only for r = 0 and r = M; for every other r it lies at least
- * 1/(2M) = 2.3e-10 from an integer.  ceil(V) = floor(V + 1 - d) for any 0 < d <= 2.3e-10 then (and
- * for integer V), and adding the integer I makes the argument positive, so truncation is the
- * floor.  The reference's three roundings (quotient, product, difference) stay within N*2^-52 <
- * 1.5e-11 of V; here N*inv is exact (N < 2^21), r*N*inv = r*N/M*(1 - 2^-62), the constant and the
- * fma round once each at magnitude < 2^18 (<= 1.5e-11 each): 2.2e-11 in all, against margins of
- * 1e-10 below and 1.3e-10 above the integer boundaries.  Adding 65536 does not change the low 16
- * bits.  Checked exhaustively over r for a set of N (and DC values), and over all N at the edge
- * draws, by tests/test_noise_shortcut.py (CPU) and by vs_ctx_selftest() on the device.
- */
-struct VsNoiseK {
-  double c, k2;
-};
-__device__ __forceinline__ VsNoiseK vs_noise_consts(int NDW, int dcs)
-{
-  VsNoiseK k;
-  k.c = (double)NDW * 0x1.00000002p-31;
-  k.k2 = ((double)(dcs + 65536) - (double)NDW / 2.0 + 1.0) - 1e-10;
-  return k;
-}
-/* the sample's int16 value is the low half of the result */
-__device__ __forceinline__ int vs_noise_sample(const VsNoiseK &k, uint32_t r)
-{
-  return (int)__builtin_fma((double)r, k.c, k.k2);
-}
-
-/*
- * The noise of one closed phase on the short sequence (T4 == 0, a width the one-fma form is proved
- * for): draw ordinal q = 0..m-1 of the cycle belongs to cycle sample T3 + q, the draws start at
- * index d0 of the lane's stream.  Two Philox blocks (8 draws) per trip; word 0 of the first block
- * has ordinal q0 in -3..0 (the scalar draws of this cycle sit in front of it), so the first trip
- * masks its leading words.  A lane that is done (q0 >= m) sends its trips to the trash rows.
- * The trips follow the Philox blocks, not the ring: a trip's 8 slots start anywhere and may wrap
- * (compare + select per sample); the run itself moves on by 8 slots per trip.  T3 + q0 >= 1:
- * VS_DF_FAST lanes have T2 >= 4.
- * TAIL: the trip in which a lane ends stops AT the end.  Without it that trip runs up to 7 slots
- * into the next cycle, which is fine when the same wavefront writes the next cycle afterwards, and
- * not when another wavefront is already writing it (three-role kernel).
- * wpos: ring slot of cycle sample 0; gbase: the utterance's sample count at cycle sample 0.
- */
-template <bool PUB, bool TAIL>
-__device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, const VsRoundKeys &rk,
-                                               const VsNoiseK nk, uint32_t d0, int m, int wpos, int T3,
-                                               int gbase, int *gpub_lane)
-{
-  const uint32_t bfirst = d0 >> 2;
-  int q0 = (int)(4u * bfirst - d0);
-  uint32_t b = bfirst;
-  VsRun8 run = vs_run8(ring, wpos, C, T3 + q0, lane);
-  char *const trashA = vs_run8_trash(ring, C, lane).A;
-  {
-    uint32_t o[8];
-    vs_philox2(b, rk, o);
-    int xv[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-    /* words in front of the cycle's first noise draw (q0 + w < 0) go to the trash rows */
-    char *A = (m > 0) ? run.A : trashA, *B = (m > 0) ? run.B : trashA;
-    uint32_t pw[8];
-    vs_wrap_select8(vs_lds_addr(A), vs_lds_addr(B), run.kw, pw);
-    const uint32_t trash32 = vs_lds_addr(trashA);
-#pragma unroll
-    for (int w = 0; w < 3; ++w) pw[w] = (q0 + w >= 0) ? pw[w] : trash32;
-    if (TAIL && __any(q0 + 8 > m)) { /* a cycle whose noise ends inside its first trip */
-#pragma unroll
-      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : trash32;
-    }
-    vs_lds_store16<0>(pw[0], xv[0]); vs_lds_store16<1>(pw[1], xv[1]); vs_lds_store16<2>(pw[2], xv[2]); vs_lds_store16<3>(pw[3], xv[3]);
-    vs_lds_store16<4>(pw[4], xv[4]); vs_lds_store16<5>(pw[5], xv[5]); vs_lds_store16<6>(pw[6], xv[6]); vs_lds_store16<7>(pw[7], xv[7]);
-    q0 += 8;
-    b += 2u;
-    vs_run8_advance(run, C);
-    if (PUB) {
-      const int done = (q0 < m) ? q0 : m;
-      VS_LDS_RELEASE();
-      __hip_atomic_store(gpub_lane, gbase + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-  int trip = 0;
-  while (__any(q0 < m)) {
-    uint32_t o[8];
-    vs_philox2(b, rk, o);
-    int xv[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) xv[w] = vs_noise_sample(nk, o[w] >> 1);
-    /* a lane that is done sends the trip to the trash rows */
-    char *A = (q0 < m) ? run.A : trashA, *B = (q0 < m) ? run.B : trashA;
-    /* the eight store addresses first, once (one compare and one select each: the ring may wrap inside
-     * the trip), then -- rarely -- the end of the cycle, then the stores */
-    uint32_t pw[8];
-    vs_wrap_select8(vs_lds_addr(A), vs_lds_addr(B), run.kw, pw);
-    if (TAIL && __any((q0 < m) && (q0 + 8 > m))) {
-      /* some lane ends inside this trip: its slots behind the end go to the trash rows too */
-      const uint32_t trash32 = vs_lds_addr(trashA);
-#pragma unroll
-      for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : trash32;
-    }
-    vs_lds_store16<0>(pw[0], xv[0]); vs_lds_store16<1>(pw[1], xv[1]); vs_lds_store16<2>(pw[2], xv[2]); vs_lds_store16<3>(pw[3], xv[3]);
-    vs_lds_store16<4>(pw[4], xv[4]); vs_lds_store16<5>(pw[5], xv[5]); vs_lds_store16<6>(pw[6], xv[6]); vs_lds_store16<7>(pw[7], xv[7]);
-    q0 += 8;
-    b += 2u;
-    vs_run8_advance(run, C);
-    ++trip;
-    if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
-      const int done = (q0 < m) ? q0 : m;
-      VS_LDS_RELEASE();
-      __hip_atomic_store(gpub_lane, gbase + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-}
-
-/*
- * Three-role kernel: what the open-phase wavefront hands to the noise wavefront for one cycle of
- * one lane -- three LDS words per lane and a sequence number.
- *   word 0 = d0                 draw index of the cycle's first noise draw
- *   word 1 = T3 | T << 16       the noise covers cycle samples [T3, T); T3 == T: nothing to add
- *   word 2 = NoiseDistWidth     (<= VS_NDW_FAST)
- *   oseq   = orders posted so far (written last; the LDS keeps it behind the three words)
- * VS_ORDER_DEPTH orders per lane may be outstanding (order k lives in box k % depth): the open-phase
- * wavefront posts the next one only when oseq - otak < depth, otak being the orders the noise
- * wavefront has taken (copied).  With one box the two wavefronts fall into lockstep and lanes that
- * just missed a batch of the noise wavefront sit out the next round (rounds at 58 % attendance
- * instead of 86 %, profiles/r03_kernel_experiments.txt).
- */
-struct VsOrderBox {
-  int *w, *oseq, *otak; /* w: [VS_ORDER_DEPTH][3][64] ints in LDS; oseq, otak: [64] */
-};
-__device__ __forceinline__ void vs_post_order(const VsOrderBox &ob, int lane, VsGen &s, uint32_t d0, int T3, int T, int NDW)
-{
-  int *box = ob.w + (s.posted & (VS_ORDER_DEPTH - 1)) * (3 * VS_WAVE) + lane;
-  box[0] = (int)d0;
-  box[VS_WAVE] = T3 | (T << 16);
-  box[2 * VS_WAVE] = NDW;
-  s.posted += 1;
-  VS_LDS_RELEASE();
-  __hip_atomic_store(&ob.oseq[lane], s.posted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-/*
- * Second half of a cycle, for every lane that is ACTIVE in the EXEC mask (the caller wraps the
- * call in "if (want)"): the samples -- statement-by-statement restatement of
- * flowgen_shimmer.c:317-423 (scalar form: oracle/vs_oracle.c).
- *
- * Two instruction sequences per phase, same results:
- *   - the general one follows the reference sample by sample (float compare against DC, the
- *     (signed short) wrap, stores masked by the end of the cycle);
- *   - the short one runs when every active lane carries VS_DF_FAST (see vs_device.h): eight
- *     samples per trip, integer compare against ceil(DC), no wrap, and stores that may run up
- *     to 7 slots past a phase -- those slots belong to a later phase of the same cycle or to the
- *     next cycle and are written again before the filter may read them (the room check of the
- *     caller leaves 8 spare slots).  One wavefront per SIMD pays ~5.3 ticks per instruction
- *     whatever its type, so instructions are what is being saved.
- * ltab is this wavefront's copy of the cos rows in LDS (rows padded to a multiple of 8 with
- * 1.0), c.tab_off the lane's row in it.
- */
-template <bool LOG, bool PUB = false, bool SPLIT = false>
-__device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t *ring, int C,
-                                              int lane, int N, const double *ltab,
-                                              vs_cycle_rec *logrow, int log_cap, VsDiag &dg,
-                                              int *gpub_lane = nullptr, const VsOrderBox ord = VsOrderBox(),
-                                              const VsRoundKeys *keys = nullptr)
-{
-  VS_DIAG_ADD(dg, 7)
-  const float Amplitude = s.amp_next;
-  const float S = s.S_next;
-  s.pend = false;
-  VS_DIAG_ADD(dg, 0)
-  const int T = s.T;
-  const int T2 = c.T2;
-  const int room = N - s.g; /* samples of this cycle that still belong to the utterance */
-  const int lim = (T < room) ? T : room; /* samples of this cycle that are emitted */
-  const double Ad = (double)Amplitude;
-  const double Ah = Ad * 0.5; /* "Amplitude * 0.5 * (...)" evaluates (Amplitude*0.5) first */
-  const float dcsf = (float)c.dcs;
-  const double *trow = ltab + c.tab_off;
-  float psum = 0.0f; /* aux of fg:374-377, accumulated from T4 on */
-  int T4 = s.T4;
-  /* the short sequences: every active lane proved in range on the host, no per-cycle log */
-  const bool fast = !LOG && __all((c.flags & VS_DF_FAST) != 0);
-  constexpr bool PREFETCH = !SPLIT;
-
-  /* ---- rising half-pulse: fg:318-324 ---- */
-  if (fast) {
-    const float dcs2 = dcsf * dcsf;
-    /* PREFETCH (a wavefront with a SIMD of its own, or one that does whole cycles): the cos values of
-     * trip i+8 are read while trip i computes -- nothing else would hide the LDS round trip.  The
-     * open-phase wavefront of the three-role kernel reads them where it needs them instead: it shares
-     * its SIMD with two others that issue while it waits, and carrying the next trip's values costs a
-     * register copy per value and trip (every instruction counts, see vs_generator_wave). */
-    double cv[8];
-    if (PREFETCH) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) cv[k] = trow[k];
-    }
-    for (int i = 0; __any(i < T2); i += 8) {
-      if (i < T2) {
-        double nv[8];
-        if (PREFETCH) {
-          if (i + 8 < T2) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) nv[k] = trow[i + 8 + k];
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) cv[k] = trow[i + k];
-        }
-        int x[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ah * (1.0 - cv[k])); /* pad: cos = 1 -> 0 */
-        if (PREFETCH) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) cv[k] = nv[k];
-        }
-        const VsRun8 run = vs_run8(ring, s.wpos, C, i, lane);
-        /* monotone flank: if the trip's first sample is not below DC none of it is.  (The stores are
-         * written out in both branches: joined behind them, the samples of the common branch would be
-         * copied into the registers the rare one leaves them in.) */
-        if (__any(x[0] < c.thr)) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const bool lt = (x[k] < c.thr) && (i + k < T2); /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
-            x[k] = lt ? c.dcs : x[k];
-            T4 = lt ? (i + k) : T4;
-            const float acc = psum + vs_sq_f(x[k]);
-            psum = lt ? dcs2 : acc;
-          }
-          vs_run8_store_all(run, x);
-          asm volatile("; rising trip with samples below DC"); /* two different tails: nothing to merge again */
-        } else {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
-          vs_run8_store_all(run, x);
-          asm volatile("; rising trip");
-        }
-      }
-    }
-  } else {
-    const int nE = (T2 < lim) ? T2 : lim; /* rising samples that are emitted */
-    int i = 0;
-    for (; i + 4 <= nE; i += 4) {
-      double v[4];
-      int xs0[4];
-      float xf0[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = trow[i + k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = 1.0 - v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = Ah * v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = ceil(v[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xs0[k] = vs_short_of(v[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xf0[k] = (float)xs0[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool lt = xf0[k] < c.DC; /* if(x[i] < par.DC) { x[i] = par.DC; T4 = i; } */
-        const int xs = lt ? c.dcs : xs0[k];
-        const float xf = lt ? dcsf : xf0[k];
-        T4 = lt ? (i + k) : T4;
-        /* aux of fg:375 runs over [T4, T3) with the FINAL T4 -- which is a T4 carried over from an
-         * earlier cycle when this cycle never goes below DC (the variable is never reset, fg:114):
-         * samples in front of it do not count */
-        psum = lt ? (xf * xf) : ((i + k >= T4) ? (psum + xf * xf) : psum);
-        ring[vs_ring_at(s.wpos, C, i + k, lane)] = (int16_t)xs;
-      }
-    }
-    for (; i < T2; ++i) { /* remainder, and (last cycle of the utterance) samples past the end */
-      const int xs0 = vs_short_of(ceil(Ah * (1.0 - trow[i])));
-      const float xf0 = (float)xs0;
-      const bool lt = xf0 < c.DC;
-      const int xs = lt ? c.dcs : xs0;
-      const float xf = lt ? dcsf : xf0;
-      T4 = lt ? i : T4;
-      psum = lt ? (xf * xf) : ((i >= T4) ? (psum + xf * xf) : psum);
-      if (i < lim) ring[vs_ring_at(s.wpos, C, i, lane)] = (int16_t)xs;
-    }
-  }
-  s.T4 = T4;
-
-  VS_DIAG_ADD(dg, 1)
-  /* ---- closing speed: fg:325, drawn in vs_cycle_scalars ---- */
-  const double Kd = (double)s.K_next;
-
-  /* ---- falling half-pulse: fg:327-332 ---- */
-  int T3 = 2 * T2;
-  {
-    bool run = true;
-    int kdone = 0; /* falling samples this lane has been through (lanes of a wave may differ in T2) */
-    if (fast) {
-      /* trips of 8, the last one possibly partial (the cos rows are padded to a multiple of 8); the
-       * flank falls monotonically, so a whole trip whose last sample is not below DC holds no break.
-       * Stores are unconditional: slots at and behind the break, and behind the flank, are written
-       * again by the closed phase (2*T2 + 8 <= T). */
-      double cv[8];
-      if (PREFETCH) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cv[k] = trow[k];
-      }
-      for (int k0 = 0; __any(run && (k0 < T2)); k0 += 8) {
-        if (run && (k0 < T2)) {
-          kdone = k0 + 8; /* >= T2 behind the last trip: nothing is left for the general sequence below */
-          double nv[8];
-          if (PREFETCH) {
-            if (k0 + 8 < T2) { /* next trip's cos values, read behind this trip's arithmetic */
-#pragma unroll
-              for (int k = 0; k < 8; ++k) nv[k] = trow[k0 + 8 + k];
-            }
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cv[k] = trow[k0 + k];
-          }
-          int x[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) x[k] = (int)ceil(Ad * ((Kd * cv[k] - Kd) + 1.0));
-          if (PREFETCH) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) cv[k] = nv[k];
-          }
-          const VsRun8 r8 = vs_run8(ring, s.wpos, C, T2 + k0, lane);
-          if (__any((x[7] < c.thr) || (k0 + 8 > T2))) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-              const bool in = k0 + k < T2;                   /* for(i = par.T2; i < 2*par.T2; i++) */
-              const bool brk = run && in && (x[k] < c.thr); /* if(x[i] < par.DC) break; */
-              T3 = brk ? (T2 + k0 + k) : T3;
-              run = run && !brk;
-              psum = (run && in) ? (psum + vs_sq_f(x[k])) : psum;
-            }
-            vs_run8_store_all(r8, x);
-            asm volatile("; falling trip with the break");
-          } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) psum += vs_sq_f(x[k]);
-            vs_run8_store_all(r8, x);
-            asm volatile("; falling trip");
-          }
-        }
-      }
-    }
-    /* general sequence: everything when !fast, nothing otherwise */
-    for (int k0 = kdone; run && (k0 < T2); k0 += 4) {
-      double v[4];
-      int xsv[4];
-      float xfv[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = trow[(k0 + k < T2) ? (k0 + k) : 0];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = Kd * v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] - Kd;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = v[k] + 1.0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = Ad * v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = ceil(v[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xsv[k] = vs_short_of(v[k]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xfv[k] = (float)xsv[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = T2 + k0 + k;
-        const bool act = run && (k0 + k < T2);
-        const bool brk = act && (xfv[k] < c.DC); /* if(x[i] < par.DC) break; */
-        T3 = brk ? i : T3;
-        run = run && !brk;
-        const bool keep = act && !brk;
-        psum = keep ? (psum + xfv[k] * xfv[k]) : psum;
-        ring[(keep && (i < lim)) ? vs_ring_at(s.wpos, C, i, lane) : vs_ring_idx(C, lane)] =
-            (int16_t)xsv[k];
-      }
-    }
-  }
-
-  VS_DIAG_ADD(dg, 2)
-  if (PUB && !(((c.flags & VS_DF_NOISE) != 0) && T4 > 0)) {
-    /* wave-specialised kernel: the open phase [0, T3) is in the ring -- let the filter wave have
-     * it while the closed phase is still being written (the LDS keeps this store behind the
-     * ring writes above).  Not when noise will still be added to [0, T4) below. */
-    VS_LDS_RELEASE();
-    __hip_atomic_store(gpub_lane, s.g + ((T3 < lim) ? T3 : lim), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  float x_pow = 0.0f, w_pow = 0.0f;
-  const bool noisy = (c.flags & VS_DF_NOISE) != 0;
-  bool handed = false; /* three-role kernel: the cycle's noise went to the noise wavefront as an order */
-
-  if (!noisy) {
-    /* ---- closed phase without noise: fg:334-336 ---- */
-    if (fast) {
-      /* trips of 8 from T3; the last one may run up to 7 slots into the next cycle */
-      for (int i = T3; __any(i < T); i += 8) {
-        const VsRun8 r8 = vs_run8_or_trash(i < T, ring, s.wpos, C, i, lane);
-        const int x[8] = {c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs, c.dcs};
-        vs_run8_store_all(r8, x);
-      }
-    } else {
-      for (int i = T3; i < lim; ++i) ring[vs_ring_at(s.wpos, C, i, lane)] = (int16_t)c.dcs;
-    }
-    VS_DIAG_ADD(dg, 3)
-  } else {
-    /* ---- closed phase with noise: fg:373-411 ---- */
-    x_pow = psum / ((float)T3 - (float)T4);
-    const float aux = (float)(1.0 + (double)(((float)T3 - (float)T4) / ((float)T)));
-    const float arg = 12.0f * aux * x_pow / c.noise;
-    const int NDW = vs_isqrt_floor((double)arg);
-    const double NDWd = (double)NDW;
-    const double half = NDWd / 2.0;
-    const int ntail = (T > T3) ? (T - T3) : 0;
-    const int m = T4 + ntail; /* draws this cycle: [0,T4) then [T3,T) */
-    const uint32_t d0 = s.d;
-    const uint32_t bfirst = d0 >> 2;
-    const int nblk = (m > 0) ? (int)(((d0 + (uint32_t)m - 1u) >> 2) - bfirst) + 1 : 0;
-    float wsum = 0.0f;
-    /* short sequence: noise only behind the pulse (T4 == 0, the usual case: DC flow 0.25 after
-     * -n), a width the one-fma form is proved for, and samples that cannot reach the clamp */
-    const int absdc = (c.dcs < 0) ? -c.dcs : c.dcs;
-    const bool nfast = fast && __all((T4 == 0) && (NDW <= VS_NDW_FAST) && ((NDW >> 1) + 2 + absdc <= 32767));
-    if (nfast) {
-      /* draw ordinal q = 0..m-1 belongs to sample T3 + q.  Two Philox blocks (8 draws) per
-       * trip; word 0 of the first block has ordinal q0 in -3..0 (the scalar draws of this cycle
-       * sit in front of it), so the first trip masks its leading words.  A lane that is done
-       * (q0 >= m) sends its trips to the trash rows; the trip in which a lane ends may run up to
-       * 7 slots into the next cycle. */
-      if (SPLIT) {
-        /* three-role kernel: the noise wavefront does this part -- post the order (the open phase
-         * is in the ring: the LDS keeps the order behind those stores) */
-        vs_post_order(ord, lane, s, d0, T3, T, NDW);
-        handed = true;
-      } else {
-        /* the lane's ten round keys: the caller's, made once per launch (the generator wavefront of the
-         * two-role kernel has the registers), or made here per cycle (the one-wave kernel has not) */
-        if (keys) {
-          vs_noise_trips<PUB, false>(ring, C, lane, *keys, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
-        } else {
-          VsRoundKeys rk;
-          vs_round_keys(c.key0, c.key1, rk);
-          vs_noise_trips<PUB, false>(ring, C, lane, rk, vs_noise_consts(NDW, c.dcs), d0, m, s.wpos, T3, s.g, gpub_lane);
-        }
-      }
-    } else if (T4 == 0) {
-      /* T4 == 0 on the general sequence: the draws map to i = T3 + q, q = 0..m-1 */
-      int mlim = lim - T3;
-      mlim = (mlim < m) ? mlim : m;
-      mlim = (mlim > 0) ? mlim : 0;
-      int slot0 = s.wpos + T3; /* ring slot of q == 0; T3 <= P + 2 < C */
-      if (slot0 >= C) slot0 -= C;
-      int q0 = (int)(4u * bfirst - d0); /* ordinal of word 0 of the first block, -3..0 */
-      /* two Philox blocks (8 draws) per trip: their dependency chains interleave */
-      for (int bi = 0; bi < nblk; bi += 2) {
-        const uint32_t b = bfirst + (uint32_t)bi;
-        uint32_t o[8];
-        vs_philox(b, c.key0, c.key1, o[0], o[1], o[2], o[3]);
-        vs_philox(b + 1u, c.key0, c.key1, o[4], o[5], o[6], o[7]);
-        double u8[8];
-        int wv8[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) u8[w] = vs_unit_of_draw(o[w] >> 1);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) u8[w] = u8[w] * NDWd;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) u8[w] = u8[w] - half;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) u8[w] = ceil(u8[w]);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) wv8[w] = vs_short_of(u8[w]);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-          const int q = q0 + w;
-          if (LOG) {
-            if ((unsigned)q < (unsigned)m) wsum += (float)wv8[w] * (float)wv8[w];
-          }
-          /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0); x[i] = truncate(DC + w) */
-          int xv = c.dcs + wv8[w];
-          xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-          const bool ok = (unsigned)q < (unsigned)mlim;
-          const unsigned sl = (unsigned)(slot0 + q), wr = sl - (unsigned)C; /* (slot0 + q) mod C */
-          const int slot = (int)((sl < wr) ? sl : wr);
-          ring[vs_ring_idx(ok ? slot : C, lane)] = (int16_t)xv;
-        }
-        q0 += 8;
-        if (PUB) {
-          const int done = (q0 < mlim) ? q0 : mlim; /* noise samples [T3, T3 + done) are written */
-          VS_LDS_RELEASE();
-          __hip_atomic_store(gpub_lane, s.g + T3 + ((done > 0) ? done : 0), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-    } else {
-      /* general case: draws cover [0,T4) then [T3,T) */
-      for (int bi = 0; bi < nblk; ++bi) {
-        const uint32_t b = bfirst + (uint32_t)bi;
-        uint32_t o0, o1, o2, o3;
-        vs_philox(b, c.key0, c.key1, o0, o1, o2, o3);
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const uint32_t ow = (w == 0) ? o0 : (w == 1) ? o1 : (w == 2) ? o2 : o3;
-          const int q = (int)(4u * b + (uint32_t)w - d0); /* ordinal of this draw in the cycle */
-          const bool act = (q >= 0) && (q < m);
-          const int i = (q < T4) ? q : (T3 + (q - T4));
-          /* w[i] = (short)ceil(((1.0*random())/RAND_MAX)*NDW - NDW/2.0), fg:387,398 */
-          const double u = vs_unit_of_draw(ow >> 1);
-          const int wv = vs_short_of(ceil(u * NDWd - half));
-          if (act) wsum += (float)wv * (float)wv;
-          /* truncate((float)x[i] + w[i]).  x[i] is (short)DC on [T3,T) by construction and, for
-           * a monotone rising flank, on [0,T4) too -- but an amplitude above 32767 wraps the
-           * (short) conversion and leaves genuine pulse samples below T4, so those are read
-           * back from the ring */
-          if (act && (i < lim)) {
-            const int idx = vs_ring_at(s.wpos, C, i, lane);
-            const int base = (q < T4) ? (int)ring[idx] : c.dcs;
-            int xv = base + wv;
-            xv = (xv > 32767) ? 32767 : ((xv < -32767) ? -32767 : xv);
-            ring[idx] = (int16_t)xv;
-          }
-        }
-      }
-    }
-    s.d = d0 + (uint32_t)m;
-    w_pow = wsum / (float)T;
-    VS_DIAG_ADD(dg, 4)
-  }
-
-  if (LOG) {
-    if (logrow && s.cyc < log_cap) {
-      vs_cycle_rec rec;
-      rec.S = S;
-      rec.x_pow = noisy ? x_pow : 0.0f;
-      rec.w_pow = noisy ? w_pow : 0.0f;
-      rec.T = T;
-      logrow[s.cyc] = rec;
-    }
-  }
-
-  /* three-role kernel: a cycle this wavefront has written in full still goes through the noise
-   * wavefront, which is the one that publishes progress to the filter -- as an empty order */
-  if (SPLIT && !handed) vs_post_order(ord, lane, s, s.d, T, T, 0);
-
-  /* ---- emit bookkeeping: fg:413-423 ---- */
-  s.cyc += 1;
-  s.g += T;
-  int wp = s.wpos + T;
-  if (wp >= C) wp -= C;
-  s.wpos = wp;
-  VS_DIAG_ADD(dg, 5)
-}
-
-/* the 8 samples of one granule / of 16 bytes of a PCM row, as integers */
-__device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
-{
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    x[2 * e] = (int)(int16_t)(v[e] & 0xFFFFu);
-    x[2 * e + 1] = (int)v[e] >> 16;
-  }
-}
-
-/*
- * One filter super-step of one lane: 24 samples of vowel_new.c:266-289 starting at the lane's
- * own position n.  x comes from the lane's ring column (rp = &ring[rslot][lane], never wraps
- * inside a super-step because ring_slots is a multiple of VS_SS and rslot advances by VS_SS
- * from 0) or, for VS_KIND_FILTER, from HBM.  The 24 int16 results leave as three
- * 16-byte stores (store_ok: lanes beyond the batch run along in the all-lanes loop of the
- * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
- * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
- */
-template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1>
-__device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
-                                             double gain, double pre, const int16_t *rp,
-                                             const int16_t *__restrict__ irow,
-                                             int16_t *__restrict__ orow, int n, int N, bool vec_ok,
-                                             int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8],
-                                             bool store_ok = true)
-{
-  /* WHOLE: the caller has taken this decision out of its loop (1: 16-byte stores, 0: sample by sample).
-   * With it -- and store_ok a constant -- nothing branches between the ring reads and their use. */
-  const bool whole = (WHOLE < 0) ? (vec_ok && (n + VS_SS <= N)) : (WHOLE != 0);
-  int xin[VS_SS];
-  if (KIND == VS_KIND_FILTER) {
-    if (whole) {
-      /* xnext[] holds this super-step's 48 bytes, loaded one super-step ago; the loads for the
-       * next one are issued now and complete behind the ~1300 instructions below (with one
-       * wave per SIMD nothing else hides an HBM round trip) */
-#pragma unroll
-      for (int k = 0; k < VS_SS / 8; ++k) vs_unpack8(xnext[k], &xin[8 * k]);
-      if (n + 2 * VS_SS <= N) {
-#pragma unroll
-        for (int k = 0; k < VS_SS / 8; ++k) xnext[k] = *(const vs_u32x4 *)(irow + n + VS_SS + 8 * k);
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < VS_SS; ++t) xin[t] = (n + t < N) ? (int)irow[n + t] : 0;
-    }
-  } else {
-    /* the first 8 now, the rest in two more batches issued from inside the sample loop (each a
-     * chunk ahead of its use): 24 ring samples held at once are 16 registers too many */
-#pragma unroll
-    for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
-  }
-
-  /* results leave in chunks of 8 samples = one 16-byte store, as soon as a chunk is complete: 24
-   * pending results would cost 24 registers (the three-role kernel runs at 168 per wavefront) */
-  auto put8 = [&](int k) {
-    if (whole) {
-      vs_u32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = PACKED ? vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1])
-                      : vs_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
-      if (store_ok) *(vs_u32x4 *)(orow + n + 8 * k) = v;
-    } else {
-#pragma unroll
-      for (int t = 8 * k; t < 8 * k + 8; ++t) {
-        int v = outv[t];
-        if (PACKED) v = (v > 32767) ? 32767 : ((v < -32767) ? -32767 : v);
-        if (store_ok && (n + t < N)) orow[n + t] = (int16_t)v;
-      }
-    }
-  };
-
-  if (KIND == VS_KIND_SOURCE) {
-#pragma unroll
-    for (int t = 8; t < VS_SS; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
-#pragma unroll
-    for (int t = 0; t < VS_SS; ++t) outv[t] = xin[t]; /* the flow itself */
-#pragma unroll
-    for (int k = 0; k < VS_SS / 8; ++k) put8(k);
-  } else {
-    const double ym1 = y[VS_SS - 1]; /* y[n-1]: only the quirk path below needs it once y[23] is replaced */
-    int qhi = 0x7FFFFFFF;            /* signed minimum of the high words of the rounded values */
-    uint32_t qlo = 0u;               /* unsigned maximum of their low words */
-#pragma unroll
-    for (int t = 0; t < VS_SS; ++t) {
-      if (KIND != VS_KIND_FILTER && (t & 7) == 0) {
-        if (t + 8 < VS_SS) {
-#pragma unroll
-          for (int u = t + 8; u < t + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
-        }
-        /* this chunk's eight samples are all "used" here: ONE s_waitcnt for the batch (the LDS answers in
-         * order) instead of one in front of every sample's first use -- to a wavefront that issues an
-         * instruction every ~5.3 ticks whatever it is, a wait that has nothing to wait for costs as much
-         * as a multiplication (tools/ubench/ubench5.hip) */
-        asm volatile("" ::"v"(xin[t]), "v"(xin[t + 1]), "v"(xin[t + 2]), "v"(xin[t + 3]), "v"(xin[t + 4]), "v"(xin[t + 5]),
-                     "v"(xin[t + 6]), "v"(xin[t + 7]));
-      }
-      /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
-      double acc;
-      const double y1 = y[(t + VS_SS - 1) % VS_SS];
-      if (ARITH == VS_ARITH_EXACT) {
-        /* y_double[0] = y_double[0] - A[j]*y_double[j], j = 1..22, each product and each
-         * difference rounded on its own.  x*gain itself is EXACT in double -- an int16 times a float
-         * gain has at most 16 + 24 significant bits -- so the first difference, x*gain - RN(A[1]*y[1]),
-         * is one fused multiply-add with the same single rounding: one instruction less per sample. */
-        acc = __builtin_fma((double)xin[t], gain, -(a[1] * y1));
-#pragma unroll
-        for (int j = 2; j <= VS_ORDER; ++j) acc = acc - a[j] * y[(t + VS_SS - j) % VS_SS];
-      } else {
-        acc = (double)xin[t] * gain;
-        /* two partial sums over the older taps (a lone wavefront issues an independent fp64
-         * instruction every ~5.3 ticks and a dependent one every ~8.4, so two alternating chains
-         * never wait), the newest tap (j = 1) last: it is the only one on the sample-to-sample
-         * critical path */
-        double p0 = acc, p1 = -(a[2] * y[(t + VS_SS - 2) % VS_SS]);
-#pragma unroll
-        for (int j = 3; j <= VS_ORDER; ++j) {
-          const double yj = y[(t + VS_SS - j) % VS_SS];
-          if (j & 1) p0 = __builtin_fma(-a[j], yj, p0);
-          else p1 = __builtin_fma(-a[j], yj, p1);
-        }
-        acc = __builtin_fma(-a[1], y1, p0 + p1);
-      }
-      /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284.  PRE1: every
-       * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
-      const double o = PRE1 ? (acc - y1)
-                            : ((ARITH == VS_ARITH_EXACT) ? (acc - pre * y1) : __builtin_fma(-pre, y1, acc));
-      /* PACKED: the caller does not look at outv[]; the clamp rides on the packing (put8) */
-      outv[t] = PACKED ? vs_round2int_half_down_unclamped(o) : vs_round2int_half_down(o);
-      /* rounded HERE: left to itself the compiler keeps all 24 arguments (48 registers) and rounds
-       * them behind the quirk test below, where the other branch does not need the results */
-      asm volatile("" : "+v"(outv[t]));
-      {
-        const int ohi = __double2hiint(o);
-        const uint32_t olo = (uint32_t)__double2loint(o);
-        qhi = (ohi < qhi) ? ohi : qhi;
-        qlo = (olo > qlo) ? olo : qlo;
-      }
-      y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
-      if ((t & 7) == 7) put8(t >> 3);
-      /* keep each sample's products next to its chain: hoisted across samples they only park
-       * in the accumulator registers and come back, two moves each way */
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu))) {
-      /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
-       * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again,
-       * literally, and store it again */
-#pragma unroll
-      for (int t = 0; t < VS_SS; ++t) {
-        const double y1 = (t == 0) ? ym1 : y[t - 1];
-        const double o = PRE1 ? (y[t] - y1)
-                              : ((ARITH == VS_ARITH_EXACT) ? (y[t] - pre * y1) : __builtin_fma(-pre, y1, y[t]));
-        outv[t] = vs_round2int(o);
-      }
-#pragma unroll
-      for (int k = 0; k < VS_SS / 8; ++k) put8(k);
-    }
-  }
-}
 
 /* per-lane constants of the generator from the lane record */
 __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsCfg &c, VsGen &s)
