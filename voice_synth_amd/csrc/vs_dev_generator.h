@@ -74,9 +74,6 @@ __device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
  * would add an s_waitcnt lgkmcnt(0), a full LDS round trip, to every noise trip). */
 #define VS_LDS_RELEASE() __atomic_signal_fence(__ATOMIC_SEQ_CST)
 
-#ifndef VS_PUB_EVERY
-#define VS_PUB_EVERY 1 /* wave-specialised kernel: the generator publishes its noise progress every N-th trip (power of two) */
-#endif
 
 /* Largest noise width the short noise sequence takes (see vs_noise_fast()). */
 #define VS_NDW_FAST 65534
@@ -169,7 +166,6 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
                          __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  int trip = 0;
   while (__any(q0 < m)) {
     uint32_t o[8];
     vs_philox2(b, rk, o);
@@ -193,8 +189,7 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
     q0 += 8;
     b += 2u;
     vs_run8_advance(run, C);
-    ++trip;
-    if (PUB && ((trip & (VS_PUB_EVERY - 1)) == 0)) {
+    if (PUB) { /* every trip: the filter may be waiting for exactly these eight samples (and the last trip of a cycle must publish) */
       const int done = (q0 < m) ? q0 : m;
       VS_LDS_RELEASE();
       __hip_atomic_store(gpub_lane, gbase + T3 + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
