@@ -178,8 +178,10 @@ __device__ __forceinline__ void vs_noise_trips(int16_t *ring, int C, int lane, c
      * the trip), then -- rarely -- the end of the cycle, then the stores */
     uint32_t pw[8];
     vs_wrap_select8(vs_lds_addr(A), vs_lds_addr(B), run.kw, pw);
-    if (TAIL && __any((q0 < m) && (q0 + 8 > m))) {
-      /* some lane ends inside this trip: its slots behind the end go to the trash rows too */
+    /* some lane ends inside this trip (1 <= m - q0 <= 7; as ONE compare: an AND of two makes the compiler
+     * turn the lane mask into 0/1 per lane and compare that against zero again): its slots behind the end
+     * go to the trash rows too */
+    if (TAIL && __any((unsigned)(m - q0 - 1) < 7u)) {
       const uint32_t trash32 = vs_lds_addr(trashA);
 #pragma unroll
       for (int w = 0; w < 8; ++w) pw[w] = (q0 + w < m) ? pw[w] : trash32;
