@@ -197,6 +197,7 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
 #define VS_KERNEL_SINGLE 1 /* one wavefront per 64 utterances generates and filters */
 #define VS_KERNEL_WS 2     /* wave-specialised: two or three wavefronts per 64 utterances, one job each */
 #define VS_FAULT_WITHHOLD_PROGRESS 1 /* tests: the generator wavefront never publishes its progress */
+#define VS_FAULT_SHORT_COS_ROWS 2    /* tests: the kernel finds no room for its cos rows (plan and kernel disagree) */
 typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
   int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */
@@ -246,8 +247,9 @@ int vs_plan_launch(vs_plan *plan, int kind, const int16_t *in_dev, size_t in_pit
                    int32_t *ncyc_dev);
 int vs_ctx_synchronize(vs_ctx *ctx);
 /* Waits for the context's stream, then reports the health word of the plan's launches:
- * VS_OK, or VS_ERR_INTERNAL if a device-side bounded wait ran out (*flags, optional, gets the
- * raw bits).  The one-call conveniences below check it themselves. */
+ * VS_OK, or VS_ERR_INTERNAL if a device-side check failed (*flags, optional, gets the raw bits:
+ * 1, 2, 4 = a bounded wait of the generator / filter / noise wavefront ran out, 8 = plan and kernel
+ * disagree about the room for the cos rows).  The one-call conveniences below check it themselves. */
 int vs_plan_status(vs_plan *plan, int *flags);
 
 /* Host cost of vs_plan_create(): host_ms = validation, parameter expansion, sorting, cosine

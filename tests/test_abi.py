@@ -66,3 +66,21 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     r = os.popen("ldd %s" % _ffi.LIB_PATH).read()
     assert "oracle" not in r
+
+
+def test_no_trap_instruction_in_the_device_code():
+    """Every "cannot happen" of the kernels ends in the launch's error word (VS_ERR_INTERNAL), never in a device
+    trap, which would take the caller's HIP context down: the gfx950 listing of the shipped flags (`make isa`)
+    holds no s_trap."""
+    import shutil
+    import subprocess
+
+    import pytest
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc on this box")
+    subprocess.run(["make", "-s", "isa"], cwd=root, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(os.path.join(root, "build", "vs_kernels.s")).read()
+    assert "vs_synth_ws_kernel" in text
+    assert not re.search(r"^\s*s_trap\b", text, flags=re.M)

@@ -141,6 +141,35 @@ def test_ws_kernel_bounded_wait_reaches_the_caller(roles):
         eng.close()
 
 
+@pytest.mark.parametrize("kernel,roles", [("single", 0), ("ws", 2), ("ws", 3)])
+def test_cos_row_disagreement_reaches_the_caller(kernel, roles):
+    """vs_tuning.fault makes the kernel believe the plan reserved no room for its cos rows: what used to be a device
+    trap (a GPU fault that takes the context down) sets bit 3 of the launch's error word, the launch runs to its end,
+    vs_plan_status / vs_synth answer VS_ERR_INTERNAL and the context stays usable"""
+    specs, fs, dur, _ = configs.config_specs(3, 200)
+    lanes, d = vs.lanes_from_specs(specs)
+    eng = vs.Engine(0)
+    try:
+        kw = dict(kernel=vs.VS_KERNEL_SINGLE) if kernel == "single" else dict(kernel=vs.VS_KERNEL_WS, ws_roles=roles)
+        eng.set_tuning(fault=vs.VS_FAULT_SHORT_COS_ROWS, **kw)
+        with pytest.raises(vs.VsError) as e:
+            eng.synth(lanes, 4000)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        plan = eng.plan(lanes, 4000)
+        out = eng.dev_alloc(200 * 4000 * 2)
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        flags = C.c_int(0)
+        rc = vs.load().vs_plan_status(plan._plan, C.byref(flags))
+        assert rc == _ffi.VS_ERR_INTERNAL and (flags.value & 8) == 8, (rc, flags.value)
+        eng.dev_free(out)
+        plan.close()
+        eng.set_tuning(**kw)
+        got = eng.synth(lanes, 4000)
+        assert np.array_equal(got, po.synth(lanes, 4000))
+    finally:
+        eng.close()
+
+
 def test_tuning_is_validated(engine):
     lib = vs.load()
     for bad in (dict(kernel=7), dict(ready_min=65), dict(ws_pairs=3), dict(gen_low=5), dict(gen_min=-1), dict(ws_roles=4),

@@ -199,6 +199,16 @@ def test_oracle_against_the_compiled_reference_over_the_option_fuzz(draw, dur):
     ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "8", "-v", "a"]),
     ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-n", "0"]),
     ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-p", "nan"]),
+    # values that overflow a float: the reference tests only the LOWER bound of -g / -n / -k (vowel_new.c:132, 142;
+    # flowgen_shimmer.c:484) and lets them pass
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-g", "1e39"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-g", "inf"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-n", "inf"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-n", "1e39"]),
+    ("vowel", ["-i", "g.wav", "-o", "o.wav", "-v", "a", "-p", "inf"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-k", "1e39"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-k", "inf"]),
+    ("flowgen_shimmer", ["-o", "g.wav", "-r", "16000", "-d", "0.5", "-j", "inf"]),
 ])
 def test_repeated_and_order_dependent_options_as_the_reference_takes_them(prog, argv):
     with tempfile.TemporaryDirectory(prefix="vsfz") as d:
@@ -213,3 +223,17 @@ def test_repeated_and_order_dependent_options_as_the_reference_takes_them(prog, 
     assert (rc == 0) == ref_ran, (argv, rc, ref.stdout[:60])
     if rc == 0 and prog == "flowgen_shimmer":
         assert cmd.dur == np.float32(argv[argv.index("-d", argv.index("-d") + 1) + 1] if argv.count("-d") > 1 else 0.5)
+
+
+def test_unbounded_options_accept_infinity_like_the_reference():
+    """-d and -g (Fg) of flowgen_shimmer have no upper bound either (flowgen_shimmer.c:472, 496: only f < 0.5 / f < 50
+    answer usage()), but the reference cannot be RUN on them: an infinite duration never ends, an infinite Fg sizes the
+    sample buffer to zero bytes (fg:569).  The parser must accept what the reference's parser accepts; the engine
+    refuses the lane afterwards (VS_ERR_UNSUPPORTED / VS_ERR_RANGE from validation), it does not call it usage()."""
+    for argv in (["-o", "g.wav", "-d", "inf"], ["-o", "g.wav", "-d", "1e39"], ["-o", "g.wav", "-g", "1e39"], ["-o", "g.wav", "-g", "inf"]):
+        rc, cmd = vs.parse_flowgen(argv)
+        assert rc == 0, argv
+    rc, cmd = vs.parse_flowgen(["-o", "g.wav", "-d", "inf"])
+    assert np.isinf(cmd.dur)
+    rc, cmd = vs.parse_flowgen(["-o", "g.wav", "-g", "1e39"])
+    assert np.isinf(cmd.lane.Fg)

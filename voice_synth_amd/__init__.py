@@ -29,6 +29,7 @@ from ._ffi import (  # noqa: F401
     VS_KERNEL_SINGLE,
     VS_KERNEL_WS,
     VS_FAULT_WITHHOLD_PROGRESS,
+    VS_FAULT_SHORT_COS_ROWS,
     check,
     load,
 )

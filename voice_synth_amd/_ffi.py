@@ -146,6 +146,7 @@ VS_KERNEL_AUTO = 0
 VS_KERNEL_SINGLE = 1
 VS_KERNEL_WS = 2
 VS_FAULT_WITHHOLD_PROGRESS = 1
+VS_FAULT_SHORT_COS_ROWS = 2
 VS_DF_FAST = 0x8
 
 

@@ -81,7 +81,11 @@ int main(int argc, char **argv)
   printf("Wait...");
 
   uint64_t n_samples = 0;
-  vs_num_samples(par->fs, cmd.dur, &n_samples); /* fg:242 */
+  rc = vs_num_samples(par->fs, cmd.dur, &n_samples); /* fg:242 */
+  if (rc != VS_OK) { /* "-d inf": the reference's conversion of the product is undefined and its loop endless */
+    fprintf(stderr, "\nflowgen_shimmer: cannot synthesise %g s at %ld Hz: %s\n", (double)cmd.dur, (long)par->fs, vs_strerror(rc));
+    return 1;
+  }
   par->seed = vs_cli_seed();                    /* replaces srandom(time(NULL)), fg:241 */
 
   vs_ctx *ctx = NULL;

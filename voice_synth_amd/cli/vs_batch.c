@@ -164,10 +164,10 @@ int main(int argc, char **argv)
     j->lane.seed = seed;
     j->lane.out_seed = seed;
     j->dur = fc.dur;
-    vs_num_samples(fc.lane.fs, fc.dur, &j->n_samples);
+    rc = vs_num_samples(fc.lane.fs, fc.dur, &j->n_samples);
     j->path = strdup(ftok[fc.wav_arg]);
     j->done = 0;
-    rc = vs_lane_validate(&j->lane);
+    if (rc == VS_OK) rc = vs_lane_validate(&j->lane);
     if (rc != VS_OK) {
       fprintf(stderr, "vs_batch: line %ld: %s\n", lineno, vs_strerror(rc));
       return 1;

@@ -66,6 +66,10 @@ int vs_lane_defaults(vs_lane *lane)
 int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples)
 {
   if (!n_samples || fs <= 0) return VS_ERR_ARG;
+  /* the same float product; a negative, infinite or NaN one (or one beyond 2^63) is undefined in the
+   * reference's conversion -- the parser lets "-d inf" pass as the reference's does, the engine stops here */
+  const float prod = (unsigned long)fs * dur;
+  if (!(prod >= 0.0f) || !(prod < 9.0e18f)) return VS_ERR_UNSUPPORTED;
   unsigned long n = (unsigned long)fs * dur;
   *n_samples = (uint64_t)n;
   return VS_OK;
@@ -178,7 +182,10 @@ typedef struct vs_opt {
   uint32_t lane_flag;  /* VS_FLAG_* raised when the option is given */
 } vs_opt;
 
-#define VS_NO_LIMIT 1e300
+/* "no upper bound" is +infinity, not a large number: the reference only tests the lower bound of these
+ * (if(f < 0.5) usage(), flowgen_shimmer.c:472, 484, 496; if(gain < 1) usage(), vowel_new.c:132, 142), and a
+ * value that overflows its float -- "1e39", "inf" -- passes there, so it must pass here: f <= HUGE_VAL. */
+#define VS_NO_LIMIT HUGE_VAL
 static const vs_opt vs_flowgen_opts[] = {
     /* in the order initialization() converts them, fg:470-546 */
     {'d', VS_CV_FLOAT, VS_TO_DUR, 0, 0.5, VS_NO_LIMIT, 0},                           /* fg:470-474 */

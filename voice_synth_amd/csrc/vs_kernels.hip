@@ -71,18 +71,28 @@ __device__ __forceinline__ void vs_load_cfg(const VsDevLane *__restrict__ L, VsC
  * for the worst wavefront of the plan (ltab_entries, same rounding).  Sets c.tab_off. */
 __device__ __forceinline__ void vs_stage_cos_rows(const VsDevLane *__restrict__ L, VsCfg &c,
                                                   double *ltab, const double *__restrict__ costab,
-                                                  int ltab_entries, int lane, bool valid)
+                                                  int ltab_entries, int lane, bool valid, const VsKernelArgs &args)
 {
   const int gtab = L->tab_off;
   int used = 0;
   bool pending = valid;
+  /* tests (vs_tuning.fault): a kernel that believes the plan reserved no room for its cos rows */
+  if (args.fault == VS_FAULT_SHORT_COS_ROWS) ltab_entries = 0;
   while (__any(pending)) {
     const unsigned long long m = __ballot(pending);
     const int leader = __builtin_ctzll(m);
     const int T2s = __builtin_amdgcn_readlane(c.T2, leader);
     const int gs = __builtin_amdgcn_readlane(gtab, leader);
     const int T2p = (T2s + 7) & ~7;
-    if (used + T2p > ltab_entries) __builtin_trap(); /* plan and kernel disagree */
+    if (used + T2p > ltab_entries) {
+      /* Plan and kernel disagree about the room for the cos rows ("cannot happen"): like every other
+       * one of those, it sets the launch's error word -- vs_plan_status() answers VS_ERR_INTERNAL -- and
+       * the launch runs to its end: the lanes that are still pending keep row offset 0 and synthesise
+       * from whatever lies there (finite garbage: every loop bound of the generator is a lane constant or
+       * comes from the draws, none from the cos values), nothing is written outside the staged region. */
+      if (args.err && lane == 0) atomicOr(args.err, 8);
+      break;
+    }
     for (int k = lane; k < T2p; k += VS_WAVE) ltab[used + k] = (k < T2s) ? costab[gs + k] : 1.0;
     if (pending && c.T2 == T2s) {
       c.tab_off = used;
@@ -123,7 +133,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   double *ltab = (double *)(ring + (size_t)(C + VS_TRASH_ROWS) * VS_GROUP_LANES); /* slots [C, C+8) are the trash rows */
   if (KIND != VS_KIND_FILTER) {
     vs_load_cfg(L, c, s);
-    vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid);
+    vs_stage_cos_rows(L, c, ltab, args.costab, args.ltab_entries, lane, valid, args);
     __syncthreads(); /* single-wave workgroup: orders the staging writes before the row reads */
   }
   vs_cycle_rec *logrow = nullptr;
@@ -298,7 +308,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
   dg.t = vs_stamp();
 #endif
   vs_load_cfg(g.L, c, s);
-  vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid);
+  vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid, args);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
   VsRoundKeys rk; /* two roles: this wavefront draws the noise itself (three: the noise wavefront has its own) */
   if (!SPLIT) vs_round_keys(c.key0, c.key1, rk);
