@@ -25,6 +25,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
                  (oracle/_ref, -O0 as its Makefile builds it, and -O2; one process pair per
                  utterance through .wav files, all host cores, driven by oracle/ref_pipelines) --
                  rank 0, N = 1 only;
+  sustained    : the same plan launched back to back for >= 2 s (outside the timed region), HIP events on the
+                 first and the last launch: the figure a compute-bound kernel holds once the chip has settled
+                 on its clock, next to the 20-step burst above (`ratio_to_timed_region`);
   other_arith  : the other arithmetic contract (fma when the run is exact), HIP events around each of
                  10 launches after 3 warm-ups, outside the timed region;
   config4      : N > 1 only -- BASELINE.json's configuration for the node: 262144 utterances x 44100
@@ -44,6 +47,7 @@ the whole batch (rms_vs_c_ref.rows_checked), since the CPU sample starts at lane
 import argparse
 import json
 import os
+import socket
 import sys
 import threading
 import time
@@ -57,7 +61,10 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes/clk x 2 flop x 2.4 
 ALGO_BYTES_PER_SAMPLE = 2       # one int16 store; the flow never reaches HBM
 FLOP_PER_SAMPLE = 48            # 22 mul + 22 sub + gain + pre-emphasis mul/sub
 GATHER_CHUNK = 16384            # utterances per chunk of the pipelined gather
-GATHER_DEADLINE_S = 150         # the gather leg may not hold the benchmark line longer than this
+SUSTAINED_S = 2.0                # back-to-back launches of the same plan for at least this long (`sustained`)
+# the config-4 block runs under a watchdog that knows its phases: a phase that shows no progress for this long is a
+# stalled exchange (bytes moved scale the allowance: 60 s + 1 s per GB into rank 0)
+PHASE_DEADLINE_S = 60
 TEARDOWN_DEADLINE_S = 60        # nor may the closing barrier hold the process once the line is printed
 
 
@@ -139,20 +146,30 @@ def reference_as_shipped(specs_fn, n_samples, max_workers, target_s=6.0):
                 sweep = {}
                 w = max_workers
                 while w >= 4:
-                    cal = run(8 * w, suffix, scratch, w)
+                    # a first look sizes the calibration: every worker count is then measured over at least
+                    # 2000 pipelines AND about a second (tens of milliseconds of 8 x w pipelines chose the count
+                    # from noise: 3478 / 2443 / 7335 per second for 8 / 16 / 32 workers in one round-3 run)
+                    quick = run(8 * w, suffix, scratch, w)
+                    n_cal = int(max(2000, min(60000, 1.0 * quick["pipelines"] / quick["seconds"])))
+                    cal = run(n_cal, suffix, scratch, w)
                     sweep[w] = round(cal["pipelines"] / cal["seconds"], 1)
                     w //= 2
                 workers = max(sweep, key=sweep.get)
+                # the measurement itself in three equal segments, so that the line carries its own spread
                 n = int(max(4096, min(400000, target_s * sweep[workers])))
-                rec = run(n, suffix, scratch, workers)
+                seg = [run((n + 2) // 3, suffix, scratch, workers) for _ in range(3)]
+            rec = {k_: sum(r_[k_] for r_ in seg) for k_ in ("pipelines", "seconds", "process_seconds_flowgen", "process_seconds_vowel")}
+            seg_rates = sorted(r_["pipelines"] / r_["seconds"] * n_samples / 1e6 for r_ in seg)
             per = rec["pipelines"] / rec["seconds"]
             out[key] = {"value": round(per * n_samples / 1e6, 2), "unit": "Msamples/s", "workers": workers,
                         "pipelines": rec["pipelines"], "seconds": round(rec["seconds"], 2),
                         "pipelines_per_s": round(per, 1),
+                        "segments_Msamples/s": {"min": round(seg_rates[0], 2), "median": round(seg_rates[1], 2), "max": round(seg_rates[2], 2)},
                         "ms_per_pipeline_per_worker": round(1e3 * workers / per, 3),
                         "ms_in_flowgen": round(1e3 * rec["process_seconds_flowgen"] / rec["pipelines"], 3),
                         "ms_in_vowel": round(1e3 * rec["process_seconds_vowel"] / rec["pipelines"], 3),
-                        "pipelines_per_s_by_workers": {str(k): v for k, v in sorted(sweep.items())}}
+                        "pipelines_per_s_by_workers": {str(k): v for k, v in sorted(sweep.items())},
+                        "calibration": ">= 2000 pipelines and >= ~1 s per worker count"}
         except Exception as exc:  # pragma: no cover - e.g. a process limit of the box
             out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
@@ -245,6 +262,21 @@ def _profile_record(name, key):
     return None
 
 
+def _profile_provenance(traffic_rec, valu_rec):
+    """The PMC figures are copied from profiles/ (a --pmc pass cannot share a run with the timed region): say which
+    tree they were taken on and whether that is THIS tree -- by content hash of the kernel sources, which the GPU box
+    can compute (it sees no .git), with the git hash the pass recorded next to it."""
+    from tools.provenance import git_head, kernel_sources_sha16
+
+    tree = kernel_sources_sha16()
+    out = {"tree_kernel_sources_sha16": tree, "tree_head": git_head()}
+    for name, rec in (("traffic", traffic_rec), ("valu", valu_rec)):
+        out[name] = None if not rec else {"profile_head": rec.get("profile_head"),
+                                          "kernel_sources_sha16": rec.get("kernel_sources_sha16"),
+                                          "matches_tree": rec.get("kernel_sources_sha16") == tree}
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -293,6 +325,15 @@ def main():
     stream = torch.cuda.current_stream(dev)
     eng = vs.Engine(local_rank, arith=arith, stream=stream.cuda_stream)
     dev_name, cus = eng.device_info()
+    # which device every rank really drives: a scaling curve is only one if N DIFFERENT devices took part
+    ident = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "pci_bus_id": eng.device_pci(),
+             "host": socket.gethostname()}
+    ranks_seen = [ident]
+    if use_dist:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, ident)
+        ranks_seen.sort(key=lambda r_: r_["rank"])
+    distinct_devices = len({(r_["host"], r_["pci_bus_id"]) for r_ in ranks_seen})
     plan = eng.plan(lanes, n_samples)                     # lane records + cos rows -> HBM
     plan_host_ms, plan_upload_ms = plan.timing()
     kernel_name = plan.kernel_name(vs.VS_KIND_SYNTH)
@@ -338,6 +379,29 @@ def main():
     n_check = per_gpu if (world == 1 and not args.no_cpu_baseline) else min(64, per_gpu)
     first_rows = out[:n_check, :n_samples].cpu().numpy() if rank == 0 else None
 
+    # ---- sustained: the same plan back to back for >= SUSTAINED_S seconds, outside the timed region.  The kernel is
+    # compute-bound and the chip settles on a lower clock under a load that lasts (DVFS); 20 steps are a 50 ms burst.
+    # HIP events on the launch stream in front of the first and behind the last launch.
+    n_sus = int(max(50, min(40000, SUSTAINED_S / max(kern_ms_avg * 1e-3, 1e-5) * 1.05)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    e0.record(stream)
+    for _ in range(n_sus):
+        launch()
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    plan.status()
+    sus_ms = e0.elapsed_time(e1)
+    st = torch.tensor([sus_ms / n_sus], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    sus_kern_ms = float(st.item())
+    sustained = {"launches": n_sus, "seconds": round(sus_ms * 1e-3, 3), "kernel_ms_avg": round(sus_kern_ms, 4),
+                 "Msamples/s": round(per_gpu * n_samples * world / (sus_kern_ms * 1e-3) / 1e6, 1),
+                 "roofline_frac": round(ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (sus_kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 "ratio_to_timed_region": round((per_gpu * n_samples * world / (sus_kern_ms * 1e-3) / 1e6) / value, 4),
+                 "how": "back-to-back launches of the timed plan, HIP events in front of the first and behind the last (max over ranks)"}
+
     # ---- the other arithmetic mode, outside the timed region: 3 warm-ups, then HIP events around
     # each of 10 launches, as in the timed region (mean, median and min reported) ----
     other = vs.VS_ARITH_FMA if arith == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
@@ -362,10 +426,16 @@ def main():
         achieved = ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e9
         key = "config%d_%s_%d" % (args.config, args.arith, per_gpu)
         rec = _profile_record("pmc_traffic.json", key)
+        sq = _profile_record("pmc_valu.json", key)
+        prov = _profile_provenance(rec, sq)
+        # counters of another tree's kernel are not this kernel's: no figure rather than a stale one
+        if rec and not prov["traffic"]["matches_tree"]:
+            rec = None
+        if sq and not prov["valu"]["matches_tree"]:
+            sq = None
         traffic = rec["hbm_bytes_per_launch"] if rec else None
         tflops = FLOP_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e12
         valu = None
-        sq = _profile_record("pmc_valu.json", key)
         if sq and kernel_name not in str(sq.get("kernel", "")):
             sq = None   # the committed counters are of another kernel: no figure rather than a mixed one
         if sq:
@@ -425,7 +495,9 @@ def main():
                               "frac": round(tflops / FP64_VALU_PEAK_TFLOPS, 4),
                               "flop_per_sample": FLOP_PER_SAMPLE},
                 "valu": valu,
+                "profile": prov,
             },
+            "sustained": sustained,
             "other_arith": {"arith": "fma" if arith == vs.VS_ARITH_EXACT else "exact",
                             "kernel": other_kernel,
                             "launches": len(other_kern),
@@ -438,7 +510,11 @@ def main():
                              "sort, cos rows; allocation + upload + wait.  Outside every timed region."},
             "launch_health_word": health,
             "device": dev_name.strip(),
+            "ranks_seen": ranks_seen,
+            "distinct_devices": distinct_devices,
         }
+        if rehearsal:
+            result["rehearsal"] = "VS_BENCH_REHEARSAL: every rank shares device 0 over gloo (tests only; the numbers mean nothing)"
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples,
                               args.cpu_seconds, first_rows)
@@ -451,10 +527,11 @@ def main():
 
     # ---- N > 1: the configuration BASELINE.json names for the node -- config 4, 262144 utterances x
     # 44100 samples cut over the N ranks -- timed like the steps above, and then the same synthesis
-    # WITH delivery of the PCM to rank 0 over RCCL, end to end.  Runs LAST and under a watchdog:
-    # should the exchange ever stall (it cannot be rehearsed with more than one rank on a one-GPU
-    # box), every rank leaves after GATHER_DEADLINE_S with a NON-ZERO exit code and rank 0 still
-    # prints the line, with the stall reported instead of the figures.
+    # WITH delivery of the PCM to rank 0 over RCCL, end to end.  Runs LAST and under a watchdog that
+    # knows the block's phases (Phases): a phase without progress for its allowance is a stalled
+    # exchange -- rank 0 prints the line with what it has and the phase's name, and every rank leaves
+    # with a NON-ZERO exit code.  A phase that FAILS on one rank (an exception, no room) is agreed on by
+    # all ranks at the phase's end and abandoned together: the line carries the error, the exit code is 0.
     out_lock = threading.Lock()
     printed = [False]
     extra = {}
@@ -467,32 +544,55 @@ def main():
                 print(json.dumps(result), flush=True)
 
     leg_done = threading.Event()
+    phases = Phases()
+
+    store = _job_store() if use_dist else None
 
     def watchdog():
-        if not leg_done.wait(GATHER_DEADLINE_S):
-            with out_lock:
-                if rank == 0 and not printed[0]:
-                    printed[0] = True
-                    result["config4"] = dict(extra.get("config4") or {}, error="no completion within %d s" % GATHER_DEADLINE_S)
-                    print(json.dumps(result), flush=True)
-            os._exit(3)   # a stalled exchange is a finding, not a success
+        abort_seen = None          # (phase name, when, message): a peer reported a failure while we were in this phase
+        while not leg_done.wait(0.5):
+            stalled = phases.stalled()
+            why = ("phase '%s': no progress for %d s" % stalled) if stalled else None
+            cur = phases.current()
+            if why is None and store is not None and cur is not None:
+                try:
+                    if store.check([ABORT_KEY]):
+                        if abort_seen is None or abort_seen[0] != cur:
+                            abort_seen = (cur, time.monotonic(), store.get(ABORT_KEY).decode(errors="replace"))
+                        elif time.monotonic() - abort_seen[1] > ABORT_GRACE_S:
+                            why = "phase '%s' abandoned: %s" % (cur, abort_seen[2])
+                except Exception:  # pragma: no cover - the store went away with its rank
+                    pass
+            if why:
+                with out_lock:
+                    if rank == 0 and not printed[0]:
+                        printed[0] = True
+                        result["config4"] = dict(phases.partial, error=why)
+                        print(json.dumps(result), flush=True)
+                os._exit(3)   # a stalled exchange is a finding, not a success
 
     if world > 1 and not args.no_config4:
         threading.Thread(target=watchdog, daemon=True).start()
         del out
         torch.cuda.empty_cache()
         try:
-            extra["config4"] = config4_block(args, eng, dev, stream, rank, world, cus, sync_all)
+            extra["config4"] = config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases)
+        except PhaseFailed as exc:
+            extra["config4"] = dict(phases.partial, error=str(exc))
         except Exception as exc:  # pragma: no cover - depends on the node
-            extra["config4"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            extra["config4"] = dict(phases.partial, error="%s: %s" % (type(exc).__name__, exc))
+        if rank == 0 and isinstance(extra.get("config4"), dict):
+            extra["config4"]["ranks_seen"] = ranks_seen
+            extra["config4"]["distinct_devices"] = distinct_devices
     leg_done.set()
     emit()
 
     if use_dist:
-        # the line is out; a peer that left early must not hold the others in the closing barrier
+        # the line is out and this rank's work is done; a peer that left early must not hold the others in
+        # the closing barrier for ever (that peer's own exit code is what fails the job)
         def leave():
             time.sleep(TEARDOWN_DEADLINE_S)
-            os._exit(4)
+            os._exit(0)
         threading.Thread(target=leave, daemon=True).start()
 
     plan.close()
@@ -502,18 +602,103 @@ def main():
         dist.destroy_process_group()
 
 
-def config4_block(args, eng, dev, stream, rank, world, cus, sync_all):
+class PhaseFailed(RuntimeError):
+    pass
+
+
+class Phases:
+    """Progress stamps of the config-4 block, read by the watchdog thread: the phase that is running, when
+    it last showed progress (entering it, or a chunk delivered: tick()), and how long it may stay silent."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._name, self._t, self._allow = None, 0.0, 0.0
+        self.partial = {}          # what the block has measured so far (goes into the line if a later phase stalls)
+
+    def enter(self, name, allow_s):
+        with self._lock:
+            self._name, self._t, self._allow = name, time.monotonic(), float(allow_s)
+
+    def tick(self):
+        with self._lock:
+            self._t = time.monotonic()
+
+    def leave(self):
+        with self._lock:
+            self._name = None
+
+    def stalled(self):
+        with self._lock:
+            if self._name is not None and time.monotonic() - self._t > self._allow:
+                return (self._name, int(self._allow))
+        return None
+
+    def current(self):
+        with self._lock:
+            return self._name
+
+
+ABORT_KEY = "vs_bench_abort"
+ABORT_GRACE_S = 10   # a rank that failed says so in the job's store; peers that are still inside the phase's own
+                     # collectives this long afterwards will never leave them by themselves
+
+
+def _job_store():
+    """the rendezvous store of the process group (a private accessor of torch.distributed: None if it moved)"""
+    try:
+        from torch.distributed import distributed_c10d
+        return distributed_c10d._get_default_store()
+    except Exception:  # pragma: no cover
+        return None
+
+
+def run_phase(phases, name, allow_s, fn, rank, dev):
+    """One phase of a multi-rank block: fn() on every rank, then an all-reduce (MIN) of an ok flag, so that a rank
+    that failed takes the others out of the block with it instead of leaving them in the NEXT collective.  Raises
+    PhaseFailed on every rank if any failed.  A rank that fails while its peers are still inside fn's own
+    collectives cannot be agreed with; it says so in the job's store, where the peers' watchdogs find it."""
+    import torch
+    import torch.distributed as dist
+
+    phases.enter(name, allow_s)
+    err, res = None, None
+    try:
+        res = fn()
+    except Exception as exc:  # noqa: BLE001 - reported in the line
+        err = exc
+        st = _job_store()
+        if st is not None:
+            try:
+                st.set(ABORT_KEY, "rank %d failed in '%s': %s: %s" % (rank, name, type(exc).__name__, exc))
+            except Exception:  # pragma: no cover
+                pass
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    phases.leave()
+    if int(ok.item()) == 0:
+        raise PhaseFailed("phase '%s' failed on %s" % (name, ("this rank (%d): %s: %s" % (rank, type(err).__name__, err)) if err
+                                                        else "another rank (see its stderr)"))
+    return res
+
+
+def config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases):
     """BASELINE.json configs[3]: 262144 utterances, mixed vowels, 22.05 kHz, 2 s, cut over the ranks in
     contiguous lane blocks (voice_synth_amd.dist.shard_range, the same cut vs_node_* makes in C), lane
     keys from the global lane index.  `value`: K launches, PCM left sharded, as the headline figure;
     `value_with_gather`: the same synthesis in chunks with every finished chunk travelling to rank 0
-    while the next one is being synthesised (PipelinedGather), timed end to end."""
+    while the next one is being synthesised (PipelinedGather), timed end to end.
+    Runs as a sequence of PHASES (see Phases / the watchdog in main): each ends with an all-reduce of an
+    ok flag, so that a rank that failed takes the others out of the block with it instead of leaving them
+    in the next collective."""
     import torch
     import torch.distributed as dist
 
     import voice_synth_amd as vs
     from voice_synth_amd import configs
     from voice_synth_amd.dist import PipelinedGather, gather_pcm, shard_range
+
+    def phase(name, allow_s, fn):
+        return run_phase(phases, name, allow_s, fn, rank, dev)
 
     total = args.config4_lanes or 262144
     lo, hi = shard_range(total, rank, world)
@@ -522,94 +707,126 @@ def config4_block(args, eng, dev, stream, rank, world, cus, sync_all):
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
     pitch = (ns + 7) & ~7
-    plan = eng.plan(lanes, ns)
-    kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
-    out = torch.empty((per, pitch), dtype=torch.int16, device=dev)
     steps = max(2, min(args.steps, 5))
+    nbytes = (total - (shard_range(total, 0, world)[1] - shard_range(total, 0, world)[0])) * ns * 2   # into rank 0
+    allow = PHASE_DEADLINE_S + nbytes / 1e9       # 60 s + 1 s per GB that has to reach rank 0
 
-    def launch():
-        plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+    def timed_steps():
+        plan = eng.plan(lanes, ns)
+        kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
+        out = torch.empty((per, pitch), dtype=torch.int16, device=dev)
 
-    for _ in range(2):
-        launch()
-    sync_all()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        launch()
-        b.record(stream)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    plan.status()
-    kern = sum(a.elapsed_time(b) for a, b in ev) / steps
-    t = torch.tensor([elapsed, kern], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern = float(t[0].item()), float(t[1].item())
-    achieved = ALGO_BYTES_PER_SAMPLE * per * ns / (kern * 1e-3) / 1e9
-    block = {"workload": label, "utterances": total, "utterances_per_gpu": per, "samples_per_utterance": ns,
-             "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
-             "value": round(total * ns * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
-             "roofline_per_gpu": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round(achieved / HBM_PEAK_GBPS, 4), "kernel": kernel,
-                                  "kernel_ms_avg": round(kern, 4)}}
-    del out
-    plan.close()
-    torch.cuda.empty_cache()
+        def launch():
+            plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+
+        for _ in range(2):
+            launch()
+        sync_all()
+        phases.tick()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(stream)
+            launch()
+            b.record(stream)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        plan.status()
+        kern = sum(a.elapsed_time(b) for a, b in ev) / steps
+        t = torch.tensor([elapsed, kern], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern = float(t[0].item()), float(t[1].item())
+        achieved = ALGO_BYTES_PER_SAMPLE * per * ns / (kern * 1e-3) / 1e9
+        del out
+        plan.close()
+        torch.cuda.empty_cache()
+        return {"workload": label, "utterances": total, "utterances_per_gpu": per, "samples_per_utterance": ns,
+                "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+                "value": round(total * ns * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+                "roofline_per_gpu": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "kernel": kernel,
+                                     "kernel_ms_avg": round(kern, 4)}}
+
+    block = phase("config-4 steps", PHASE_DEADLINE_S, timed_steps)
+    phases.partial = dict(block)
     if args.no_gather:
         return block
 
     # ---- with delivery to rank 0 ----
-    # every rank must take the same decision, or the peers would wait for a root that gave up: rank 0
-    # checks that the gathered PCM fits (twice: overlapped + comparison), the verdict is all-reduced
-    need = 2 * total * ns * 2 + (2 << 30)
-    fits = torch.tensor([1 if (rank != 0 or torch.cuda.mem_get_info(dev)[0] > need) else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(fits, op=dist.ReduceOp.MIN)
-    if int(fits.item()) == 0:
-        block["gather"] = {"error": "rank 0 has no room for %d bytes of gathered PCM" % need}
+    state = {}
+
+    def gather_setup():
+        # rank 0 needs room for the gathered PCM twice (overlapped + comparison); a rank without room RAISES and
+        # the agreement at the end of the phase takes every rank out together
+        need = 2 * total * ns * 2 + (2 << 30)
+        if rank == 0 and torch.cuda.mem_get_info(dev)[0] <= need:
+            raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
+        state["pg"] = PipelinedGather(total, ns, GATHER_CHUNK, dev)
+        state["plans"] = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), ns)
+                          for a_, b_ in state["pg"].edges]
+
+    try:
+        phase("gather set-up (buffers, chunk plans)", PHASE_DEADLINE_S, gather_setup)
+    except PhaseFailed as exc:
+        block["gather"] = {"error": str(exc)}
         return block
-    pg = PipelinedGather(total, ns, GATHER_CHUNK, dev)
-    plans = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), ns) for a_, b_ in pg.edges]
+    pg, plans = state["pg"], state["plans"]
 
     def launch_chunk(kk, tensor):
         plans[kk].launch(vs.VS_KIND_SYNTH, tensor.data_ptr(), out_pitch=ns)
 
-    pg.run(launch_chunk)          # warm-up pass (RCCL connections, code objects)
-    sync_all()
-    g0 = time.perf_counter()
-    full_pcm = pg.run(launch_chunk)
-    sync_all()
-    g = time.perf_counter() - g0
-    gt = torch.tensor([g], dtype=torch.float64, device=dev)
-    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-    g = float(gt.item())
-    for p_ in plans:
-        p_.status()
-    nbytes = (total - (shard_range(total, 0, world)[1] - shard_range(total, 0, world)[0])) * ns * 2
-    block["value_with_gather"] = round(total * ns / g / 1e6, 1)
-    gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
-              "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
-              "ingress_GB/s": round(nbytes / g / 1e9, 1),
-              "backend": dist.get_backend(),
-              "transport": "torch.distributed send/recv (backend above; nccl = RCCL over xGMI), one grouped receive per chunk on the root"}
-    # the un-overlapped comparison: the same chunks, then one gather behind them
-    sync_all()
-    g0 = time.perf_counter()
-    for kk, tns in enumerate(pg.chunks):
-        launch_chunk(kk, tns)
-    torch.cuda.synchronize(dev)
-    again = gather_pcm(pg.base, total, dst=0)
-    sync_all()
-    g2 = time.perf_counter() - g0
-    gt = torch.tensor([g2], dtype=torch.float64, device=dev)
-    dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-    gather["ms_compute_then_gather"] = round(float(gt.item()) * 1e3, 3)
-    if rank == 0:
-        gather["equals_unoverlapped_gather"] = bool(torch.equal(again, full_pcm))
-    del again, full_pcm
-    for p_ in plans:
-        p_.close()
-    block["gather"] = gather
+    def warm():
+        pg.run(launch_chunk, progress=phases.tick)          # warm-up pass (RCCL connections, code objects)
+        sync_all()
+
+    def timed_gather():
+        g0 = time.perf_counter()
+        full_pcm = pg.run(launch_chunk, progress=phases.tick)
+        sync_all()
+        g = time.perf_counter() - g0
+        gt = torch.tensor([g], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        for p_ in plans:
+            p_.status()
+        return float(gt.item()), full_pcm
+
+    def compare(full_pcm):
+        # the un-overlapped comparison: the same chunks, then one gather behind them
+        sync_all()
+        g0 = time.perf_counter()
+        for kk, tns in enumerate(pg.chunks):
+            launch_chunk(kk, tns)
+        torch.cuda.synchronize(dev)
+        phases.tick()
+        again = gather_pcm(pg.base, total, dst=0)
+        sync_all()
+        g2 = time.perf_counter() - g0
+        gt = torch.tensor([g2], dtype=torch.float64, device=dev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(again, full_pcm)) if rank == 0 else None
+        return float(gt.item()), same
+
+    try:
+        phase("gather warm-up (first RCCL exchange)", allow, warm)
+        g, full_pcm = phase("gather, overlapped (timed)", allow, timed_gather)
+        block["value_with_gather"] = round(total * ns / g / 1e6, 1)
+        gather = {"overlapped": True, "chunk_utterances": GATHER_CHUNK, "chunks_per_gpu": len(pg.edges),
+                  "ms_compute_and_gather": round(g * 1e3, 3), "bytes_into_rank0": nbytes,
+                  "ingress_GB/s": round(nbytes / g / 1e9, 1),
+                  "backend": dist.get_backend(),
+                  "transport": "torch.distributed send/recv (backend above; nccl = RCCL over xGMI), one grouped receive per chunk on the root"}
+        block["gather"] = gather
+        phases.partial = dict(block)
+        g2, same = phase("gather, compute then gather (comparison)", allow, lambda: compare(full_pcm))
+        gather["ms_compute_then_gather"] = round(g2 * 1e3, 3)
+        if rank == 0:
+            gather["equals_unoverlapped_gather"] = same
+        del full_pcm
+    except PhaseFailed as exc:
+        block.setdefault("gather", {})["error"] = str(exc)
+    finally:
+        for p_ in plans:
+            p_.close()
     return block
 
 

@@ -221,6 +221,9 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
 int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures);
 /* Name, CU count of the device in use. */
 int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count);
+/* PCI bus id of the device in use ("0000:05:00.0", hipDeviceGetPCIBusId): what tells two devices of a node
+ * apart when a multi-GPU run has to show that N DIFFERENT devices took part (bench.py, vs_bench). */
+int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len);
 
 /* ---- plans: host preparation once, any number of launches ---------------------------- */
 

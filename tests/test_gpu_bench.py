@@ -19,12 +19,27 @@ def _check(line, steps):
     d = json.loads(line)
     for k in KEYS:
         assert k in d, k
-    assert d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["scaling"] == "weak"
+    assert d["unit"] == "Msamples/s" and d["steps"] == steps and d["scaling"] == "weak"
     assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] > 0
     assert d["launch_health_word"] == 0                     # vs_plan_status after the timed launches
+    # the sustained figure next to the burst: >= 2 s of back-to-back launches of the same plan
+    sus = d["sustained"]
+    assert sus["seconds"] >= 1.9 and sus["launches"] >= 50 and sus["kernel_ms_avg"] > 0
+    assert abs(sus["ratio_to_timed_region"] - sus["Msamples/s"] / d["value"]) < 2e-3
+    # PMC figures are copied from profiles/: they say which tree they are from, and are null when it is not this one
+    prof = r["profile"]
+    assert len(prof["tree_kernel_sources_sha16"]) == 16
+    for name in ("traffic", "valu"):
+        if r[name] is not None:
+            assert prof[name]["matches_tree"] is True and prof[name]["profile_head"]
+        if prof[name] is not None and not prof[name]["matches_tree"]:
+            assert r[name] is None
+    # every rank says which device it drove
+    assert len(d["ranks_seen"]) == d["n_gpus"] and d["distinct_devices"] >= 1
+    assert all(len(x["pci_bus_id"]) >= 7 for x in d["ranks_seen"])
     assert d["plan"]["host_ms"] >= 0 and d["plan"]["upload_ms"] >= 0
     return d
 
@@ -79,6 +94,9 @@ def test_bench_two_ranks_rehearsal_on_one_device():
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["utterances_per_gpu"] == 4096
+    # the line shows WHICH devices took part: two ranks, and -- rehearsal -- one device between them
+    assert [x["rank"] for x in d["ranks_seen"]] == [0, 1] and d["distinct_devices"] == 1 and "rehearsal" in d
+    assert d["config4"]["distinct_devices"] == 1
     # whole-job value = the units of both ranks over the slowest rank's time
     assert abs(d["value"] - 2 * 4096 * 16000 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) / d["value"] < 0.01
     assert "cpu_baseline" not in d              # rank 0 at N = 1 only

@@ -282,3 +282,35 @@ static size_t n;
     r = subprocess.run(["gcc", "-std=gnu11", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-unused-function",
                         "-Wno-unused-but-set-variable", "-I", os.path.join(root, "include"), str(path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_profile_provenance_nulls_counters_of_another_tree(tmp_path):
+    """bench.py copies HBM traffic and SQ counters out of profiles/pmc_*.json (a --pmc pass cannot share a run with the
+    timed region): each record names the tree it was taken on (kernel_sources_sha16 + profile_head) and bench.py keeps a
+    figure only when that is the tree it runs from"""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from tools import provenance
+
+    tree = provenance.kernel_sources_sha16()
+    assert len(tree) == 16 and tree == provenance.kernel_sources_sha16()
+    same = {"hbm_bytes_per_launch": 1.0, "kernel_sources_sha16": tree, "profile_head": "abc1234"}
+    other = {"hbm_bytes_per_launch": 1.0, "kernel_sources_sha16": "0" * 16, "profile_head": "0ld0ld0"}
+    old_style = {"hbm_bytes_per_launch": 1.0}
+    p = bench._profile_provenance(same, other)
+    assert p["tree_kernel_sources_sha16"] == tree
+    assert p["traffic"]["matches_tree"] is True and p["traffic"]["profile_head"] == "abc1234"
+    assert p["valu"]["matches_tree"] is False
+    assert bench._profile_provenance(old_style, None)["traffic"]["matches_tree"] is False
+    assert bench._profile_provenance(None, None)["valu"] is None
+    # the content hash follows the kernel sources: one byte more in a copy of the tree changes it
+    import shutil
+    for d in provenance.SOURCE_DIRS:
+        shutil.copytree(os.path.join(root, d), tmp_path / d)
+    assert provenance.kernel_sources_sha16(str(tmp_path)) == tree
+    with open(tmp_path / "voice_synth_amd" / "csrc" / "vs_device.h", "a") as f:
+        f.write("\n")
+    assert provenance.kernel_sources_sha16(str(tmp_path)) != tree

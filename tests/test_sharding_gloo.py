@@ -101,3 +101,70 @@ def test_two_rank_gather_equals_single_rank(tmp_path):
     lanes, d = vs.lanes_from_specs(specs)
     want = po.synth(lanes, vs.num_samples(fs, d), threads=2)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+# ---- bench.py's multi-rank control flow (no device needed: the phases only need torch.distributed) ----
+
+def _worker_phases(rank, world, port, out_dir, mode):
+    import json
+    import sys
+    import time
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    phases = bench.Phases()
+    rec = {"rank": rank}
+    try:
+        rec["first"] = bench.run_phase(phases, "fine", 30, lambda: rank * 10, rank, "cpu")
+        if mode == "one_rank_raises":
+            def fn():
+                if rank == 1:
+                    raise MemoryError("no room on rank 1")
+                return "ok"
+            try:
+                bench.run_phase(phases, "second", 30, fn, rank, "cpu")
+                rec["second"] = "passed"
+            except bench.PhaseFailed as exc:
+                rec["second"] = str(exc)
+            # every rank is still in step: a later collective works
+            t = torch.tensor([rank + 1])
+            dist.all_reduce(t)
+            rec["after"] = int(t.item())
+        elif mode == "silent_phase":
+            phases.enter("silent", 0.4)
+            time.sleep(0.1)
+            rec["early"] = phases.stalled()
+            phases.tick()
+            time.sleep(0.3)
+            rec["after_tick"] = phases.stalled()       # 0.3 s since the tick: still inside the allowance
+            time.sleep(0.3)
+            rec["late"] = list(phases.stalled() or [])
+            phases.leave()
+            rec["left"] = phases.stalled()
+    finally:
+        json.dump(rec, open(os.path.join(out_dir, "r%d.json" % rank), "w"))
+        dist.destroy_process_group()
+
+
+def test_a_phase_that_fails_on_one_rank_takes_all_ranks_out_together(tmp_path):
+    """bench.py's config-4 block runs in phases that end with an all-reduce of an ok flag (run_phase): rank 1 raising
+    inside a phase must end the phase with PhaseFailed on EVERY rank -- nobody is left behind in the next collective"""
+    import json
+    mp.spawn(_worker_phases, args=(2, _free_port(), str(tmp_path), "one_rank_raises"), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / ("r%d.json" % r))) for r in (0, 1))
+    assert r0["first"] == 0 and r1["first"] == 10
+    assert "another rank" in r0["second"] and "no room on rank 1" in r1["second"]
+    assert r0["after"] == 3 and r1["after"] == 3
+
+
+def test_watchdog_stamps(tmp_path):
+    """Phases: the watchdog sees a phase as stalled only once it has shown no progress for its allowance; tick() is
+    progress; outside a phase nothing is ever stalled"""
+    import json
+    mp.spawn(_worker_phases, args=(1, _free_port(), str(tmp_path), "silent_phase"), nprocs=1, join=True)
+    r = json.load(open(tmp_path / "r0.json"))
+    assert r["early"] is None and r["after_tick"] is None and r["late"] == ["silent", 0] and r["left"] is None

@@ -17,6 +17,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tools.provenance import stamp  # noqa: E402  (which tree the pass ran on: profile_head + kernel_sources_sha16)
 
 
 def per_kernel(path):
@@ -60,6 +62,7 @@ def main():
             "write_bytes": write,
             "hbm_bytes_per_launch": fetch + write,
         }
+        data[key].update(stamp())
     elif mode == "valu":
         args = sys.argv[2:]
         want = ""
@@ -86,6 +89,7 @@ def main():
         # effective clock (MI355X_MICROARCH.md, DVFS): GRBM_GUI_ACTIVE is summed over the 8 XCDs
         if "GRBM_GUI_ACTIVE_per_launch" in rec and "kernel_ns_under_profiler_median" in rec:
             rec["clock_GHz_under_profiler"] = rec["GRBM_GUI_ACTIVE_per_launch"] / 8.0 / rec["kernel_ns_under_profiler_median"]
+        rec.update(stamp())
         data[key] = rec
     else:
         sys.exit(__doc__)

@@ -198,6 +198,12 @@ class Engine:
         check(self._lib.vs_ctx_device_info(self._ctx, name, 128, C.byref(cu)), "vs_ctx_device_info")
         return name.value.decode(), cu.value
 
+    def device_pci(self):
+        """PCI bus id of the device in use ("0000:05:00.0")"""
+        buf = C.create_string_buffer(32)
+        check(self._lib.vs_ctx_device_pci(self._ctx, buf, 32), "vs_ctx_device_pci")
+        return buf.value.decode()
+
     # ---- host-buffer conveniences ----
     def synth(self, lanes, n_samples):
         arr = _as_lane_array(lanes)

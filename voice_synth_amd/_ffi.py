@@ -176,6 +176,7 @@ SYMBOLS = {
     "vs_ctx_set_tuning": (C.c_int, [_vp, _P(Tuning)]),
     "vs_ctx_selftest": (C.c_int, [_vp, _P(C.c_uint64)]),
     "vs_ctx_device_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _P(C.c_int)]),
+    "vs_ctx_device_pci": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "vs_plan_create": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _P(_vp)]),
     "vs_plan_destroy": (None, [_vp]),
     "vs_plan_launch": (

@@ -61,6 +61,28 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   ctx->cu_count = prop.multiProcessorCount;
   memset(&ctx->tuning, 0, sizeof(ctx->tuning));
   memset(&ctx->pool, 0, sizeof(ctx->pool));
+  /* The HIP runtime sets up its copy path (staging buffers, the transfer queue of this device) at a
+   * process's first host-to-device copy: 8 ms on a bare process, ~100 ms in one that has loaded PyTorch
+   * (profiles/r04_plan_cost.txt).  Paid HERE, once per context, so that the first vs_plan_create of a
+   * process costs what every later one costs. */
+  {
+    void *scratch = nullptr;
+    const size_t warm_bytes = 1u << 20;
+    void *host = malloc(warm_bytes);
+    hipError_t e = host ? hipMalloc(&scratch, warm_bytes) : hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      memset(host, 0, warm_bytes);
+      e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, nullptr);
+      if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      (void)hipFree(scratch);
+    }
+    free(host);
+    if (e != hipSuccess) {
+      delete ctx;
+      return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
+    }
+  }
   /* Experiments only (tools/gpu_sweep.sh): with VS_DEBUG_TUNING=1 in the environment the knobs
    * are read ONCE, here, and go through the same validation as vs_ctx_set_tuning().  Without it
    * no environment variable can change what the library launches. */
@@ -139,6 +161,15 @@ extern "C" int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len
   if (!ctx) return VS_ERR_ARG;
   if (name && name_len) snprintf(name, name_len, "%s", ctx->name);
   if (cu_count) *cu_count = ctx->cu_count;
+  return VS_OK;
+}
+
+extern "C" int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len)
+{
+  if (!ctx || !bus_id || len < 16) return VS_ERR_ARG;
+  bus_id[0] = '\0';
+  const hipError_t e = hipDeviceGetPCIBusId(bus_id, (int)len, ctx->device);
+  if (e != hipSuccess) return VS_ERR_HIP;
   return VS_OK;
 }
 
@@ -667,7 +698,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   hipStream_t up = ctx->upload ? ctx->upload : ctx->stream;
   if (e == hipSuccess && wide)
     e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, up);
-  if (e == hipSuccess) e = hipMemsetAsync(p->d_err, 0, sizeof(int), up);
+  static const int zero_word = 0; /* a copy, not hipMemsetAsync: a process's first memset loads the runtime's fill kernel (20 ms) */
+  if (e == hipSuccess) e = hipMemcpyAsync(p->d_err, &zero_word, sizeof(int), hipMemcpyHostToDevice, up);
   if (e == hipSuccess)
     e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
   if (e == hipSuccess && !costab.empty())

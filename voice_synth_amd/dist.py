@@ -83,8 +83,10 @@ class PipelinedGather:
         self.chunks = [base[a:b] for a, b in self.edges]
         self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
 
-    def run(self, launch):
-        """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done."""
+    def run(self, launch, progress=None):
+        """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done.
+        progress (optional) is called once per round of chunks handed to the transport and once per completed
+        transfer: a watchdog's sign of life (bench.py)."""
         work = []
         peers = [r for r in range(self.world) if r != self.dst]
         peer_edges = {}
@@ -122,8 +124,12 @@ class PipelinedGather:
                             work += dist.batch_isend_irecv(ops)
                     else:
                         work += dist.batch_isend_irecv(ops)
+            if progress:
+                progress()
         for w in work:
             w.wait()
+            if progress:
+                progress()
         if self.cuda:
             self.comm_stream.synchronize()
             torch.cuda.current_stream().synchronize()
