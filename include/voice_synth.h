@@ -198,6 +198,8 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
 #define VS_KERNEL_WS 2     /* wave-specialised: two or three wavefronts per 64 utterances, one job each */
 #define VS_FAULT_WITHHOLD_PROGRESS 1 /* tests: the generator wavefront never publishes its progress */
 #define VS_FAULT_SHORT_COS_ROWS 2    /* tests: the kernel finds no room for its cos rows (plan and kernel disagree) */
+#define VS_FAULT_SHARD_PREPARE 3     /* tests: a context that serves a shard of a node fails to prepare its chunks (vs_node_synth_gather) */
+#define VS_FAULT_SHARD_HANDOVER 4    /* tests: ... fails while handing its first chunk over, after the others have started */
 typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
   int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */

@@ -145,12 +145,17 @@ def test_vs_bench_runs_from_plain_c():
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["utterances_per_gpu"] == 3000 and d["value"] > 100
     assert d["links"] == ["self", "self"]
+    # the line says which devices took part (two logical shards = ONE device) and that the gathered PCM is what one
+    # device gives alone, row for row
+    assert len(d["devices"]) == 2 and d["devices"][0] == d["devices"][1] and d["distinct_devices"] == 1
+    assert d["gathered_equals_one_device"] is True and d["rows_verified_against_one_device"] == 6000
     # host code in C + RCCL gather, as far as one device goes: a one-rank communicator owned by the node
     r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "2", "--warmup", "1", "--gpus", "1", "--rccl"],
                        capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-    assert d["n_gpus"] == 1 and d["value"] > 100
+    assert d["n_gpus"] == 1 and d["value"] > 100 and d["links"] == ["self"]
+    assert d["gathered_equals_one_device"] is True and d["rows_verified_against_one_device"] == 3000
     # ... and logical shards of one device are refused, loudly
     r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "1", "--warmup", "0", "--gpus", "2", "--rccl"],
                        capture_output=True, timeout=300, env=dict(os.environ, VS_DEVICES="0,0"))

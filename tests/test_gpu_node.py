@@ -122,3 +122,87 @@ def test_links_and_the_rccl_transport_on_one_device(engine, batch):
         assert e.value.code == _ffi.VS_ERR_UNSUPPORTED
     finally:
         node.close()
+
+
+SENTINEL = 0x5A5A
+
+
+def _fill(engine, ptr, n_words):
+    engine.dev_upload(ptr, np.full(n_words, SENTINEL, dtype=np.uint16).view(np.int16))
+
+
+def test_a_shard_that_cannot_prepare_stops_every_shard(engine, batch):
+    """The exchange is all or nothing: the shard threads meet after ALL chunk plans of ALL shards exist; one shard that
+    failed keeps every shard from enqueueing anything (no kernel, no copy, no send, no receive) -- an unmatched
+    ncclSend / ncclRecv would never complete.  vs_tuning.fault on one shard's context provokes it: the call returns
+    that shard's error and not one word of the root buffer has been written."""
+    lanes, ns, want = batch
+    n = len(lanes)
+    root = engine.dev_alloc(n * ns * 2)
+    node = vs.Node([0] * 4)
+    try:
+        _fill(engine, root, n * ns)
+        node.set_shard_tuning(2, fault=vs.VS_FAULT_SHARD_PREPARE)
+        with pytest.raises(vs.VsError) as e:
+            node.synth_gather(lanes, ns, root, ns, vs.Node.OVERLAP | vs.Node.STAGE_ALL)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        got = engine.dev_download(root, (n, ns)).view(np.uint16)
+        assert (got == SENTINEL).all()
+        node.set_shard_tuning(2)
+        node.synth_gather(lanes, ns, root, ns, vs.Node.OVERLAP | vs.Node.STAGE_ALL)
+        assert np.array_equal(engine.dev_download(root, (n, ns)), want)
+    finally:
+        node.close()
+        engine.dev_free(root)
+
+
+@pytest.mark.parametrize("shard", [0, 3])
+def test_a_shard_that_fails_at_its_first_handover_ends_the_call(engine, batch, shard):
+    """A failure BEHIND the meeting point (a launch or a send refused): the failing thread ends the exchange, every
+    other shard stops at its next chunk, the call returns the error instead of waiting for transfers that will never
+    be matched, and the node works again afterwards."""
+    lanes, ns, want = batch
+    n = len(lanes)
+    root = engine.dev_alloc(n * ns * 2)
+    node = vs.Node([0] * 4)
+    try:
+        node.set_shard_tuning(shard, fault=vs.VS_FAULT_SHARD_HANDOVER)
+        with pytest.raises(vs.VsError) as e:
+            node.synth_gather(lanes, ns, root, ns, vs.Node.OVERLAP | vs.Node.STAGE_ALL)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        node.set_shard_tuning(shard)
+        node.synth_gather(lanes, ns, root, ns, vs.Node.OVERLAP | vs.Node.STAGE_ALL)
+        assert np.array_equal(engine.dev_download(root, (n, ns)), want)
+    finally:
+        node.close()
+        engine.dev_free(root)
+
+
+def test_rccl_exchange_aborted_on_failure_falls_back_to_the_peer_transport(engine, batch):
+    """What one GPU can show of the abort path: with the RCCL transport chosen, a failure behind the meeting point calls
+    ncclCommAbort on the node's communicator(s); the node is back on the peer transport afterwards, a new communicator
+    can be made, and the gather through it is right again."""
+    lanes, ns, want = batch
+    n = len(lanes)
+    root = engine.dev_alloc(n * ns * 2)
+    node = vs.Node([0])
+    try:
+        node.set_transport(vs.Node.TRANSPORT_RCCL)
+        node.set_shard_tuning(0, fault=vs.VS_FAULT_SHARD_HANDOVER)
+        with pytest.raises(vs.VsError) as e:
+            node.synth_gather(lanes, ns, root, ns)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        node.set_shard_tuning(0)
+        # back on the peer transport: a pitched root buffer (which RCCL refuses) is accepted again
+        pitched = engine.dev_alloc(n * (ns + 8) * 2)
+        try:
+            node.synth_gather(lanes, ns, pitched, ns + 8)
+            assert np.array_equal(engine.dev_download(pitched, (n, ns + 8))[:, :ns], want)
+        finally:
+            engine.dev_free(pitched)
+        node.set_transport(vs.Node.TRANSPORT_RCCL)
+        node.synth_gather(lanes, ns, root, ns)
+        assert np.array_equal(engine.dev_download(root, (n, ns)), want)
+    finally:
+        node.close()
+        engine.dev_free(root)

@@ -314,3 +314,49 @@ def test_profile_provenance_nulls_counters_of_another_tree(tmp_path):
     with open(tmp_path / "voice_synth_amd" / "csrc" / "vs_device.h", "a") as f:
         f.write("\n")
     assert provenance.kernel_sources_sha16(str(tmp_path)) != tree
+
+
+def test_gather_bookkeeping_ragged_cuts_and_more_shards_than_chunks():
+    """The rounds of vs_node_synth_gather (csrc/vs_host.c: vs_shard_cut, vs_gather_rounds, vs_gather_round -- plain C,
+    walked by the sending shards and by the receiving root alike): every row of every shard travels exactly once, in
+    order, in chunks of at most `chunk` rows; shards with fewer chunks than there are rounds (or with no lanes at all)
+    sit the later rounds out; the cut equals voice_synth_amd.configs.shard_range."""
+    from voice_synth_amd.configs import shard_range
+
+    lib = vs.load()
+    lib.vs_gather_rounds.restype = C.c_size_t
+    lib.vs_gather_rounds.argtypes = [C.c_size_t, C.c_int, C.c_size_t]
+    lib.vs_gather_round.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.vs_shard_cut.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    cases = [(262144, 8, 16384), (65536, 8, 16384), (100000, 8, 16384), (13, 3, 2), (5, 8, 16384), (1, 4, 1), (16385, 2, 16384),
+             (3 * 16384 + 1, 3, 16384), (7, 7, 3), (1000, 3, 16384), (2 ** 33 + 5, 8, 16384)]
+    for n, shards, chunk in cases:
+        rounds = lib.vs_gather_rounds(n, shards, chunk)
+        seen_total = 0
+        for s in range(shards):
+            lo, hi = C.c_size_t(), C.c_size_t()
+            assert lib.vs_shard_cut(n, shards, s, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == tuple(shard_range(n, s, shards))
+            own_chunks = (hi.value - lo.value + chunk - 1) // chunk
+            assert own_chunks <= rounds
+            nxt = lo.value
+            probe = range(rounds + 2) if rounds < 64 else list(range(3)) + list(range(rounds - 2, rounds + 2))
+            for k in probe:
+                r0, rows = C.c_size_t(), C.c_size_t()
+                assert lib.vs_gather_round(n, shards, s, chunk, k, C.byref(r0), C.byref(rows)) == 0
+                if k < own_chunks:
+                    assert r0.value == lo.value + k * chunk and 1 <= rows.value <= chunk and r0.value + rows.value <= hi.value
+                    if rounds < 64:
+                        assert r0.value == nxt
+                        nxt += rows.value
+                else:
+                    assert rows.value == 0
+            if rounds < 64:
+                assert nxt == hi.value
+            seen_total += hi.value - lo.value
+        assert seen_total == n
+        assert rounds == (shard_range(n, 0, shards)[1] + chunk - 1) // chunk
+    r0, rows = C.c_size_t(), C.c_size_t()
+    assert lib.vs_gather_round(10, 2, 2, 4, 0, C.byref(r0), C.byref(rows)) == _ffi.VS_ERR_ARG      # no such shard
+    assert lib.vs_gather_round(10, 2, 0, 0, 0, C.byref(r0), C.byref(rows)) == _ffi.VS_ERR_ARG      # no chunk size
+    assert lib.vs_gather_round(10, 2, 0, 4, 2 ** 62, C.byref(r0), C.byref(rows)) == 0 and rows.value == 0   # no wrap

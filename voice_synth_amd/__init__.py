@@ -30,6 +30,8 @@ from ._ffi import (  # noqa: F401
     VS_KERNEL_WS,
     VS_FAULT_WITHHOLD_PROGRESS,
     VS_FAULT_SHORT_COS_ROWS,
+    VS_FAULT_SHARD_PREPARE,
+    VS_FAULT_SHARD_HANDOVER,
     check,
     load,
 )
@@ -339,6 +341,18 @@ class Node:
         if v < 0:
             raise VsError(v, "vs_node_link")
         return self.LINKS[v]
+
+    def set_shard_tuning(self, shard, **kw):
+        """vs_ctx_set_tuning() on the context that serves one shard (vs_node_ctx); no keywords resets"""
+        ctx = C.c_void_p()
+        check(self._lib.vs_node_ctx(self._node, int(shard), C.byref(ctx)), "vs_node_ctx")
+        if not kw:
+            check(self._lib.vs_ctx_set_tuning(ctx, None), "vs_ctx_set_tuning")
+            return
+        t = Tuning()
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        check(self._lib.vs_ctx_set_tuning(ctx, C.byref(t)), "vs_ctx_set_tuning")
 
     def shard_range(self, n_lanes, shard):
         lo, hi = C.c_size_t(), C.c_size_t()

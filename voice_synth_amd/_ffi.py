@@ -147,6 +147,8 @@ VS_KERNEL_SINGLE = 1
 VS_KERNEL_WS = 2
 VS_FAULT_WITHHOLD_PROGRESS = 1
 VS_FAULT_SHORT_COS_ROWS = 2
+VS_FAULT_SHARD_PREPARE = 3
+VS_FAULT_SHARD_HANDOVER = 4
 VS_DF_FAST = 0x8
 
 

@@ -1,7 +1,7 @@
 /*
  * vs_bench -- the throughput of the fused source->filter path from plain C, no Python:
  *
- *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl]]
+ *     vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl] [--no-verify]]
  *
  * Workload: BASELINE.json configs[2] -- N utterances (default 65536), vowel table "12467"[lane % 5],
  * 16 kHz, 1 s, jitter 1 %, shimmer 0.5 dB (-s 5.76), glottal noise 20 dB, lane key = 1 + lane --
@@ -15,6 +15,9 @@
  * of the next one; the line then also carries the slowest shard's compute time and how every
  * shard reaches the root ("links").  --rccl: the chunks travel by ncclSend / ncclRecv on a communicator
  * the node object owns (vs_node_set_transport) instead of peer DMA -- host code in C, RCCL gather.
+ * After the timed steps the gathered PCM is compared, row by row, with what device 0 gives when it synthesises the same
+ * lanes alone ("gathered_equals_one_device"; --no-verify skips it), and the line lists the PCI bus id of the device
+ * behind every shard ("devices", "distinct_devices").
  * One line of JSON on stdout.  bench.py remains the driver's benchmark; this is the same
  * measurement for a maintainer who only has the C side.
  */
@@ -32,7 +35,7 @@ static double now_s(void)
 int main(int argc, char **argv)
 {
   size_t n_lanes = 65536;
-  int steps = 20, warmup = 5, host = 0, gpus = 0, use_rccl = 0;
+  int steps = 20, warmup = 5, host = 0, gpus = 0, use_rccl = 0, verify = 1;
   const char *arith = "exact";
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "--lanes") && i + 1 < argc) n_lanes = (size_t)strtoull(argv[++i], NULL, 0);
@@ -42,8 +45,9 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "--host")) host = 1;
     else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--rccl")) use_rccl = 1;
+    else if (!strcmp(argv[i], "--no-verify")) verify = 0;
     else {
-      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl]]\n");
+      fprintf(stderr, "usage: vs_bench [--lanes N] [--steps K] [--warmup W] [--arith exact|fma] [--host] [--gpus G [--rccl] [--no-verify]]\n");
       return 1;
     }
   }
@@ -97,6 +101,20 @@ int main(int argc, char **argv)
       const int l = vs_node_link(node, d);
       snprintf(links + strlen(links), sizeof(links) - strlen(links), "%s\"%s\"", d ? ", " : "", (l >= 0 && l < 4) ? names[l] : "?");
     }
+    /* which device serves each shard: a node run must show that `gpus` DIFFERENT devices took part */
+    char pcis[64 * 24 + 4] = "";
+    char seen[64][32];
+    int distinct = 0;
+    for (int d = 0; rc == VS_OK && d < gpus; d++) {
+      vs_ctx *c = NULL;
+      char id[32] = "?";
+      rc = vs_node_ctx(node, d, &c);
+      if (rc == VS_OK) (void)vs_ctx_device_pci(c, id, sizeof(id));
+      snprintf(pcis + strlen(pcis), sizeof(pcis) - strlen(pcis), "%s\"%s\"", d ? ", " : "", id);
+      int known = 0;
+      for (int e = 0; e < distinct; e++) known = known || !strcmp(seen[e], id);
+      if (!known) snprintf(seen[distinct++], sizeof(seen[0]), "%s", id);
+    }
     if (rc == VS_OK) rc = vs_node_ctx(node, 0, &root);
     if (rc == VS_OK) rc = vs_dev_alloc(root, n_lanes * n_samples * sizeof(int16_t), &out);
     for (int k = 0; rc == VS_OK && k < warmup + steps; k++) {
@@ -106,14 +124,49 @@ int main(int argc, char **argv)
         if (shard_ms > worst_shard) worst_shard = shard_ms;
       }
     }
+    /* the gathered PCM against ONE device synthesising the same lanes alone, chunk by chunk (a lane's draws are
+     * keyed by the seed in its record, so the cut over the devices must not show: flowgen_shimmer.c:121-122,
+     * vowel_new.c:90 -- nothing but per-utterance state exists) */
+    size_t rows_verified = 0, rows_differ = 0;
+    if (rc == VS_OK && verify) {
+      const size_t chunk = 16384 < n_lanes ? 16384 : n_lanes;
+      int16_t *a = (int16_t *)malloc(chunk * n_samples * sizeof(int16_t));
+      int16_t *b = (int16_t *)malloc(chunk * n_samples * sizeof(int16_t));
+      void *scratch = NULL;
+      if (!a || !b) rc = VS_ERR_NOMEM;
+      if (rc == VS_OK) rc = vs_dev_alloc(root, chunk * n_samples * sizeof(int16_t), &scratch);
+      for (size_t r0 = 0; rc == VS_OK && r0 < n_lanes; r0 += chunk) {
+        const size_t rows = (n_lanes - r0 < chunk) ? (n_lanes - r0) : chunk;
+        vs_plan *plan = NULL;
+        rc = vs_plan_create(root, lanes + r0, rows, n_samples, &plan);
+        if (rc == VS_OK) rc = vs_plan_launch(plan, VS_KIND_SYNTH, NULL, 0, (int16_t *)scratch, n_samples, NULL, 0, NULL);
+        if (rc == VS_OK) rc = vs_plan_status(plan, NULL);
+        if (rc == VS_OK) rc = vs_dev_download(root, a, scratch, rows * n_samples * sizeof(int16_t));
+        if (rc == VS_OK) rc = vs_dev_download(root, b, (char *)out + r0 * n_samples * sizeof(int16_t), rows * n_samples * sizeof(int16_t));
+        for (size_t r = 0; rc == VS_OK && r < rows; r++)
+          rows_differ += memcmp(a + r * n_samples, b + r * n_samples, n_samples * sizeof(int16_t)) != 0;
+        if (rc == VS_OK) rows_verified += rows;
+        if (plan) vs_plan_destroy(plan);
+      }
+      if (scratch) vs_dev_free(root, scratch);
+      free(a);
+      free(b);
+      if (rc == VS_OK && rows_differ) {
+        fprintf(stderr, "vs_bench: %zu of %zu gathered rows differ from what one device gives\n", rows_differ, rows_verified);
+        rc = VS_ERR_INTERNAL;
+      }
+    }
     if (rc != VS_OK) fprintf(stderr, "vs_bench: %s\n", vs_strerror(rc));
     else
       printf("{\"metric\": \"synthesised Msamples/s (whole node), PCM gathered into device %d\", \"value\": %.1f, "
              "\"unit\": \"Msamples/s\", \"n_gpus\": %d, \"ms_per_step\": %.4f, \"slowest_shard_compute_ms\": %.4f, "
              "\"steps\": %d, \"warmup\": %d, \"utterances_per_gpu\": %zu, \"samples_per_utterance\": %llu, "
-             "\"arith\": \"%s\", \"links\": [%s], \"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
+             "\"arith\": \"%s\", \"links\": [%s], \"devices\": [%s], \"distinct_devices\": %d, \"rows_verified_against_one_device\": %zu, "
+             "\"gathered_equals_one_device\": %s, "
+             "\"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
              devs[0], (double)n_lanes * (double)n_samples * steps / (sum_ms * 1e-3) / 1e6, gpus, sum_ms / steps, worst_shard,
-             steps, warmup, per_gpu, (unsigned long long)n_samples, arith, links);
+             steps, warmup, per_gpu, (unsigned long long)n_samples, arith, links, pcis, distinct, rows_verified,
+             verify ? "true" : "null");
     if (out) vs_dev_free(root, out);
     vs_node_destroy(node);
     free(lanes);

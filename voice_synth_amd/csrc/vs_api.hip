@@ -126,7 +126,7 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->gen_low != 0 && t->gen_low < VS_SS) return VS_ERR_ARG;
   if (t->gen_min < 0 || t->gen_min > 64) return VS_ERR_ARG;
   if (t->spin_limit < 0) return VS_ERR_ARG;
-  if (t->fault != 0 && t->fault != VS_FAULT_WITHHOLD_PROGRESS && t->fault != VS_FAULT_SHORT_COS_ROWS) return VS_ERR_ARG;
+  if (t->fault < 0 || t->fault > VS_FAULT_SHARD_HANDOVER) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
   ctx->tuning = *t;

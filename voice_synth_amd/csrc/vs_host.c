@@ -421,3 +421,48 @@ int vs_wav_header_read(const unsigned char *buf, size_t avail, int32_t *fs, int 
   }
   return VS_ERR_IO;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The bookkeeping of a node's gather (vs_node_synth_gather, csrc/vs_node.hip), without any device in
+ * it: which lanes a shard owns, and which of its rows travel to the root in which round.  The sender
+ * (a shard working through its chunks) and the receiver (the root posting one group of receives per
+ * round) BOTH walk these functions, so the two sides of the exchange agree by construction;
+ * tests/test_host_logic.py goes through ragged cuts, more shards than chunks and empty shards.
+ * Utterances are independent (flowgen_shimmer.c:121-122, vowel_new.c:90): any cut is a valid cut.
+ * ---------------------------------------------------------------------------------------- */
+/* lanes [*lo, *hi) of shard `shard` of `n_shards`: contiguous blocks that differ by at most one lane
+ * (the same cut voice_synth_amd/configs.py::shard_range makes for the one-process-per-GPU path) */
+int vs_shard_cut(size_t n_lanes, int n_shards, int shard, size_t *lo, size_t *hi)
+{
+  if (!lo || !hi || n_shards <= 0 || shard < 0 || shard >= n_shards) return VS_ERR_ARG;
+  const size_t S = (size_t)n_shards, s = (size_t)shard;
+  const size_t base = n_lanes / S, rem = n_lanes % S;
+  *lo = s * base + (s < rem ? s : rem);
+  *hi = *lo + base + (s < rem ? 1 : 0);
+  return VS_OK;
+}
+/* rounds a gather in chunks of `chunk` utterances takes: the chunks of the LARGEST shard */
+size_t vs_gather_rounds(size_t n_lanes, int n_shards, size_t chunk)
+{
+  if (n_shards <= 0 || chunk == 0) return 0;
+  size_t lo, hi;
+  vs_shard_cut(n_lanes, n_shards, 0, &lo, &hi); /* shard 0 is never smaller than another */
+  return (hi - lo + chunk - 1) / chunk;
+}
+/* rows [*row0, *row0 + *rows) of the batch that shard `shard` hands over in round `round`; *rows == 0: none
+ * (the shard has fewer chunks than there are rounds, or no lanes at all) */
+int vs_gather_round(size_t n_lanes, int n_shards, int shard, size_t chunk, size_t round, size_t *row0, size_t *rows)
+{
+  size_t lo, hi;
+  if (!row0 || !rows || chunk == 0) return VS_ERR_ARG;
+  const int rc = vs_shard_cut(n_lanes, n_shards, shard, &lo, &hi);
+  if (rc != VS_OK) return rc;
+  *row0 = lo;
+  *rows = 0;
+  if (round > (hi - lo) / chunk) return VS_OK;   /* keeps round * chunk from wrapping */
+  const size_t a = lo + round * chunk;
+  if (a >= hi) return VS_OK;
+  *row0 = a;
+  *rows = (hi - a < chunk) ? (hi - a) : chunk;
+  return VS_OK;
+}

@@ -94,6 +94,17 @@ struct vs_plan {
                                   flow buffer is the context pool's instead of one allocation per chunk */
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                         int mode, vs_plan **out);
+/* bookkeeping of a node's gather (csrc/vs_host.c, plain C): the cut of a batch over the shards and the rows
+ * that travel in each round; walked by the sending shards AND by the receiving root */
+#ifdef __cplusplus
+extern "C" {
+#endif
+int vs_shard_cut(size_t n_lanes, int n_shards, int shard, size_t *lo, size_t *hi);
+size_t vs_gather_rounds(size_t n_lanes, int n_shards, size_t chunk);
+int vs_gather_round(size_t n_lanes, int n_shards, int shard, size_t chunk, size_t round, size_t *row0, size_t *rows);
+#ifdef __cplusplus
+}
+#endif
 /* grows *ptr (device memory) to at least bytes; VS_OK or VS_ERR_HIP */
 int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes);
 /* creates the delivery streams, events and pinned staging buffers (at least row_bytes each) on first use */

@@ -28,9 +28,20 @@
  *   VS_NODE_TRANSPORT_RCCL  one RCCL communicator over the node's (distinct) devices, owned by the
  *                           node object: a finished chunk leaves by ncclSend on the shard's copy
  *                           stream, the root posts the matching ncclRecv of every peer's chunk k as
- *                           one group, each on the stream of that peer's link -- point-to-point over
- *                           xGMI, no ring.  librccl is opened with dlopen() when this transport is
- *                           chosen, so that the two drop-in programs do not pay for loading it.
+ *                           ONE group on ONE stream -- RCCL fuses the point-to-point operations of a
+ *                           group into one launch whose channels run the seven transfers side by side
+ *                           (one per xGMI link, no ring); streams do not add to that.  librccl is
+ *                           opened with dlopen() when this transport is chosen, so that the two
+ *                           drop-in programs do not pay for loading it.
+ *
+ * The exchange is ALL OR NOTHING (vs_node_synth_gather): every shard first creates the plans of all
+ * of its chunks; the shard threads then meet, and only if every one of them succeeded does anybody
+ * enqueue a kernel, a copy, a send or a receive -- an unmatched ncclSend / ncclRecv never completes,
+ * and a stream that holds one can never be waited for.  A failure AFTER that point (a launch or a
+ * send refused) aborts the node's communicators (ncclCommAbort, which ends the kernels of the
+ * operations in flight), every thread stops at its next chunk, the call returns the error and the
+ * node is back on the peer transport.  Which rows travel in which round is plain C without a device
+ * in it (vs_gather_round, csrc/vs_host.c), walked by sender and receiver alike.
  *
  * One host thread per shard (a vs_ctx is used by one thread at a time).  The multi-PROCESS form
  * of the same scheme -- one rank per GPU under torch.distributed.run, RCCL send/recv of the
@@ -41,7 +52,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -57,6 +71,7 @@ struct VsRccl {
   void *lib;
   int (*CommInitAll)(vs_nccl_comm *, int, const int *);
   int (*CommDestroy)(vs_nccl_comm);
+  int (*CommAbort)(vs_nccl_comm);
   int (*Send)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t);
   int (*Recv)(void *, size_t, int, int, vs_nccl_comm, hipStream_t);
   int (*GroupStart)(void);
@@ -70,10 +85,11 @@ struct vs_node {
   std::vector<hipStream_t> compute, copy;
   std::vector<hipEvent_t> ev_done[2], ev_copied[2];
   std::vector<int> link;       /* VS_NODE_LINK_* of every shard */
+  std::vector<int> base_link;  /* ... as found at creation (self / peer / staged): what the peer transport uses */
   int transport;               /* VS_NODE_TRANSPORT_* */
   VsRccl rccl;
   std::vector<vs_nccl_comm> comm;      /* one per shard (rank = shard), RCCL transport only */
-  std::vector<hipStream_t> recv;       /* on the root device: one stream per peer link */
+  std::vector<hipStream_t> recv;       /* on the root device: THE stream the root's receive groups are posted on */
   int last_rccl_error;
 };
 
@@ -120,6 +136,7 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
       }
     }
     nd->link.push_back(link);
+    nd->base_link.push_back(link);
   }
   if (rc != VS_OK) {
     vs_node_destroy(nd);
@@ -153,8 +170,7 @@ extern "C" int vs_node_set_transport(vs_node *nd, int transport)
   if (transport == VS_NODE_TRANSPORT_PEER) {
     vs_node_drop_rccl(nd);
     nd->transport = transport;
-    for (size_t s = 0; s < nd->link.size(); s++)
-      if (nd->link[s] == VS_NODE_LINK_RCCL) nd->link[s] = VS_NODE_LINK_PEER;
+    nd->link = nd->base_link;
     return VS_OK;
   }
   /* RCCL puts one rank on one device: logical shards of one device cannot form a communicator */
@@ -188,11 +204,12 @@ extern "C" int vs_node_set_transport(vs_node *nd, int transport)
   if (!R.lib) return VS_ERR_UNSUPPORTED;
   R.CommInitAll = (int (*)(vs_nccl_comm *, int, const int *))dlsym(R.lib, "ncclCommInitAll");
   R.CommDestroy = (int (*)(vs_nccl_comm))dlsym(R.lib, "ncclCommDestroy");
+  R.CommAbort = (int (*)(vs_nccl_comm))dlsym(R.lib, "ncclCommAbort");
   R.Send = (int (*)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclSend");
   R.Recv = (int (*)(void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclRecv");
   R.GroupStart = (int (*)(void))dlsym(R.lib, "ncclGroupStart");
   R.GroupEnd = (int (*)(void))dlsym(R.lib, "ncclGroupEnd");
-  if (!R.CommInitAll || !R.CommDestroy || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
+  if (!R.CommInitAll || !R.CommDestroy || !R.CommAbort || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
     vs_node_drop_rccl(nd);
     return VS_ERR_UNSUPPORTED;
   }
@@ -204,9 +221,10 @@ extern "C" int vs_node_set_transport(vs_node *nd, int transport)
     vs_node_drop_rccl(nd);
     return VS_ERR_HIP;
   }
-  /* the root receives every peer on a stream of its own: one per xGMI link */
+  /* the root posts its receive groups on ONE stream of its own (concurrency inside a group of
+   * point-to-point operations comes from RCCL's channels, not from streams) */
   hipError_t he = hipSetDevice(nd->device[0]);
-  for (size_t s = 0; s < S && he == hipSuccess; s++) {
+  if (he == hipSuccess) {
     hipStream_t st = nullptr;
     he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     nd->recv.push_back(st);
@@ -264,13 +282,11 @@ extern "C" int vs_node_set_arith(vs_node *nd, int arith)
   return VS_OK;
 }
 
-/* lanes [lo, hi) of shard s: contiguous blocks that differ by at most one lane -- the same cut as
- * voice_synth_amd/dist.py::shard_range makes for the one-process-per-GPU path */
+/* lanes [lo, hi) of shard s: the cut of csrc/vs_host.c (vs_shard_cut), which the one-process-per-GPU
+ * path makes too (voice_synth_amd/configs.py::shard_range) */
 static void shard_range(size_t n_lanes, size_t shards, size_t s, size_t *lo, size_t *hi)
 {
-  const size_t base = n_lanes / shards, rem = n_lanes % shards;
-  *lo = s * base + std::min(s, rem);
-  *hi = *lo + base + (s < rem ? 1 : 0);
+  (void)vs_shard_cut(n_lanes, (int)shards, (int)s, lo, hi);
 }
 
 extern "C" int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard, size_t *lo, size_t *hi)
@@ -281,8 +297,37 @@ extern "C" int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard,
 }
 
 namespace {
+/* where the shard threads of one gather meet: between "all of my chunk plans exist" and "the first
+ * kernel / copy / send / receive is enqueued" */
+struct GatherSync {
+  std::mutex m;
+  std::condition_variable cv;
+  size_t parties = 0, waiting = 0;
+  unsigned generation = 0;
+  bool ok = true;                    /* cleared by a shard that failed to prepare */
+  std::atomic<bool> aborted{false};  /* set by a shard that failed once the exchange had started */
+  std::mutex abort_m;
+
+  /* every shard calls this once; returns the verdict of all of them */
+  bool arrive(bool mine)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    if (!mine) ok = false;
+    const unsigned gen = generation;
+    if (++waiting == parties) {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+    return ok;
+  }
+};
+
 struct ShardJob {
   vs_node *nd;
+  GatherSync *sync;
   size_t s;
   const vs_lane *lanes;
   size_t lo, hi, n_samples, n_total;
@@ -293,58 +338,95 @@ struct ShardJob {
   double compute_ms;  /* host clock: first launch .. last kernel done */
 };
 
+/* A shard failed after the exchange had started: peers may hold sends nobody will receive, the root
+ * receives nobody will send.  ncclCommAbort ends the kernels of the operations in flight, so that the
+ * streams they sit on can be waited for again; the communicators are gone afterwards (the caller of
+ * vs_node_synth_gather drops the transport).  Once per gather, whoever comes first. */
+void abort_exchange(vs_node *nd, GatherSync *sync)
+{
+  std::lock_guard<std::mutex> lk(sync->abort_m);
+  if (sync->aborted.exchange(true)) return;
+  if (nd->transport != VS_NODE_TRANSPORT_RCCL) return;
+  for (size_t p = 0; p < nd->comm.size(); p++) {
+    if (nd->comm[p]) {
+      (void)nd->rccl.CommAbort(nd->comm[p]);
+      nd->comm[p] = nullptr;
+    }
+  }
+}
+
 void shard_gather(ShardJob *j)
 {
   vs_node *nd = j->nd;
+  GatherSync *sync = j->sync;
   const size_t s = j->s;
+  const size_t S = nd->ctx.size();
   vs_ctx *ctx = nd->ctx[s];
   j->rc = VS_OK;
   j->compute_ms = 0.0;
-  if (j->lo >= j->hi) return;
-  if (hipSetDevice(nd->device[s]) != hipSuccess) {
-    j->rc = VS_ERR_HIP;
-    return;
-  }
-  VsPool &P = ctx->pool;
+  const bool rccl = nd->transport == VS_NODE_TRANSPORT_RCCL;
   const size_t rows_all = j->hi - j->lo;
   /* the root's own shard is synthesised in place, in ONE launch: nothing travels, so there is
-   * nothing to overlap, and a whole shard fills the chip where a chunk fills a quarter of it */
-  const bool rccl = nd->transport == VS_NODE_TRANSPORT_RCCL;
+   * nothing to overlap, and a whole shard fills the chip where a chunk fills a quarter of it.  (Its
+   * receives are posted behind that launch: the peers' first chunks are not finished before the
+   * root's own kernel is either) */
   const bool in_place = (nd->device[s] == nd->device[0]) && !((j->flags & VS_NODE_STAGE_ALL) && !rccl);
-  const size_t chunk = in_place ? rows_all : std::min<size_t>(rows_all, VS_NODE_CHUNK);
+  const size_t chunk = in_place ? std::max<size_t>(rows_all, 1) : VS_NODE_CHUNK;
   /* an RCCL message is one contiguous range: chunks are synthesised at pitch n_samples and land in a
    * root buffer of that pitch (checked by the caller) */
   const size_t pitch = rccl ? j->n_samples : ((j->n_samples + 7) & ~(size_t)7);
-  if (!in_place) {
-    for (int k = 0; k < 2 && (k == 0 || rows_all > chunk); k++) {
-      j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], chunk * pitch * sizeof(int16_t));
-      if (j->rc != VS_OK) return;
-    }
-  }
+  VsPool &P = ctx->pool;
   hipStream_t saved = ctx->stream;
-  ctx->stream = nd->compute[s];
   std::vector<vs_plan *> plans;
-  struct Pending { size_t row0, rows; int k; };
-  std::vector<Pending> later;
+  struct Chunk { size_t row0, rows; };
+  std::vector<Chunk> chunks;
+
+  /* ---- prepare: buffers and the plans of ALL chunks; nothing is enqueued yet ---- */
+  if (hipSetDevice(nd->device[s]) != hipSuccess) j->rc = VS_ERR_HIP;
+  if (j->rc == VS_OK && rows_all > 0) {
+    for (size_t round = 0;; round++) {
+      size_t row0 = 0, rows = 0;
+      if (in_place) {
+        if (round > 0) break;
+        row0 = j->lo;
+        rows = rows_all;
+      } else if (vs_gather_round(j->n_total, (int)S, (int)s, VS_NODE_CHUNK, round, &row0, &rows) != VS_OK || rows == 0) {
+        break;
+      }
+      chunks.push_back({row0, rows});
+    }
+    if (!in_place) {
+      for (int k = 0; k < 2 && j->rc == VS_OK && (k == 0 || chunks.size() > 1); k++)
+        j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], std::min(rows_all, chunk) * pitch * sizeof(int16_t));
+    }
+    ctx->stream = nd->compute[s];
+    for (size_t c = 0; c < chunks.size() && j->rc == VS_OK; c++) {
+      vs_plan *plan = nullptr;
+      j->rc = vs_plan_create_impl(ctx, j->lanes + chunks[c].row0, chunks[c].rows, j->n_samples, VS_PLAN_POOL_SCRATCH, &plan);
+      if (j->rc == VS_OK) plans.push_back(plan);
+    }
+    if (j->rc == VS_OK && ctx->tuning.fault == VS_FAULT_SHARD_PREPARE) j->rc = VS_ERR_INTERNAL; /* tests */
+  }
+  /* ---- all or nothing: one shard that cannot go on keeps every shard from starting ---- */
+  const bool go = sync->arrive(j->rc == VS_OK);
+
   const auto t0 = std::chrono::steady_clock::now();
-  int k = 0;
   bool used[2] = {false, false};
-  for (size_t r0 = j->lo; r0 < j->hi && j->rc == VS_OK; r0 += chunk, k ^= 1) {
-    const size_t rows = std::min(chunk, j->hi - r0);
-    vs_plan *plan = nullptr;
-    j->rc = vs_plan_create_impl(ctx, j->lanes + r0, rows, j->n_samples, VS_PLAN_POOL_SCRATCH, &plan);
-    if (j->rc != VS_OK) break;
-    plans.push_back(plan);
+  int k = 0;
+  for (size_t c = 0; go && c < chunks.size() && j->rc == VS_OK && !sync->aborted.load(); c++, k ^= 1) {
+    const size_t r0 = chunks[c].row0, rows = chunks[c].rows;
     int16_t *dst = j->root + r0 * j->root_pitch;
     if (in_place) {
-      j->rc = vs_plan_launch(plan, VS_KIND_SYNTH, nullptr, 0, dst, j->root_pitch, nullptr, 0, nullptr);
+      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, nullptr, 0, dst, j->root_pitch, nullptr, 0, nullptr);
+      if (j->rc == VS_OK && ctx->tuning.fault == VS_FAULT_SHARD_HANDOVER) j->rc = VS_ERR_INTERNAL; /* tests */
       continue;
     }
     /* the buffer must have been copied out before it is overwritten */
     hipError_t e = hipSuccess;
     if (used[k]) e = hipStreamWaitEvent(nd->compute[s], nd->ev_copied[k][s], 0);
     if (e == hipSuccess) {
-      j->rc = vs_plan_launch(plan, VS_KIND_SYNTH, nullptr, 0, (int16_t *)P.d_out[k], pitch, nullptr, 0, nullptr);
+      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, nullptr, 0, (int16_t *)P.d_out[k], pitch, nullptr, 0, nullptr);
+      if (j->rc == VS_OK && c == 0 && ctx->tuning.fault == VS_FAULT_SHARD_HANDOVER) j->rc = VS_ERR_INTERNAL; /* tests */
       if (j->rc != VS_OK) break;
       e = hipEventRecord(nd->ev_done[k][s], nd->compute[s]);
     }
@@ -382,26 +464,17 @@ void shard_gather(ShardJob *j)
       j->rc = VS_ERR_HIP;
     }
   }
-  if (rccl && s == 0 && j->rc == VS_OK && nd->ctx.size() > 1) {
-    /* the root's side of the exchange: chunk k of every peer as one group, each receive on the
-     * stream of that peer's link, straight into the peer's rows of the root buffer */
-    const size_t S = nd->ctx.size();
-    size_t rounds = 0;
-    for (size_t p = 1; p < S; p++) {
-      size_t lo, hi;
-      shard_range(j->n_total, S, p, &lo, &hi);
-      rounds = std::max(rounds, (hi - lo + VS_NODE_CHUNK - 1) / VS_NODE_CHUNK);
-    }
-    for (size_t kk = 0; kk < rounds && j->rc == VS_OK; kk++) {
+  if (go && rccl && s == 0 && j->rc == VS_OK && S > 1) {
+    /* the root's side of the exchange: round k = chunk k of every peer that has one, as one group on
+     * one stream, straight into the peer's rows of the root buffer */
+    const size_t rounds = vs_gather_rounds(j->n_total, (int)S, VS_NODE_CHUNK);
+    for (size_t kk = 0; kk < rounds && j->rc == VS_OK && !sync->aborted.load(); kk++) {
       int ne = nd->rccl.GroupStart();
       for (size_t p = 1; p < S && ne == 0; p++) {
-        size_t lo, hi;
-        shard_range(j->n_total, S, p, &lo, &hi);
-        const size_t r0 = lo + kk * VS_NODE_CHUNK;
-        if (r0 >= hi) continue;
-        const size_t rows = std::min<size_t>(VS_NODE_CHUNK, hi - r0);
+        size_t r0 = 0, rows = 0;
+        if (vs_gather_round(j->n_total, (int)S, (int)p, VS_NODE_CHUNK, kk, &r0, &rows) != VS_OK || rows == 0) continue;
         ne = nd->rccl.Recv(j->root + r0 * j->root_pitch, rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, (int)p,
-                           nd->comm[0], nd->recv[p]);
+                           nd->comm[0], nd->recv[0]);
       }
       const int ge = nd->rccl.GroupEnd();
       if (ne == 0) ne = ge;
@@ -410,24 +483,22 @@ void shard_gather(ShardJob *j)
         j->rc = VS_ERR_HIP;
       }
     }
-    for (size_t p = 1; p < S; p++) {
-      const hipError_t re = hipStreamSynchronize(nd->recv[p]);
-      if (re != hipSuccess && j->rc == VS_OK) {
-        ctx->last_hip_error = (int)re;
-        j->rc = VS_ERR_HIP;
-      }
+  }
+  /* a failure behind the meeting point: the others have started, end what is in flight */
+  if (go && j->rc != VS_OK) abort_exchange(nd, sync);
+  if (go && hipSetDevice(nd->device[s]) == hipSuccess) {
+    hipError_t e = hipStreamSynchronize(nd->compute[s]);
+    j->compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
+    if (e == hipSuccess && rccl && s == 0 && !nd->recv.empty()) e = hipStreamSynchronize(nd->recv[0]);
+    if (e != hipSuccess && j->rc == VS_OK) {
+      ctx->last_hip_error = (int)e;
+      j->rc = VS_ERR_HIP;
     }
-  }
-  hipError_t e = hipStreamSynchronize(nd->compute[s]);
-  j->compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
-  if (e != hipSuccess && j->rc == VS_OK) {
-    ctx->last_hip_error = (int)e;
-    j->rc = VS_ERR_HIP;
-  }
-  for (vs_plan *pl : plans) {
-    const int st = vs_plan_status(pl, nullptr);
-    if (j->rc == VS_OK && st != VS_OK) j->rc = st;
+    for (vs_plan *pl : plans) {
+      const int st = vs_plan_status(pl, nullptr);
+      if (j->rc == VS_OK && st != VS_OK && !sync->aborted.load()) j->rc = st;
+    }
   }
   for (vs_plan *pl : plans) vs_plan_destroy(pl);
   ctx->stream = saved;
@@ -444,10 +515,13 @@ extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_
   const size_t S = nd->ctx.size();
   std::vector<ShardJob> jobs(S);
   std::vector<std::thread> th;
+  GatherSync sync;
+  sync.parties = S;
   const auto t0 = std::chrono::steady_clock::now();
   for (size_t s = 0; s < S; s++) {
     ShardJob &j = jobs[s];
     j.nd = nd;
+    j.sync = &sync;
     j.s = s;
     j.lanes = lanes;
     shard_range(n_lanes, S, s, &j.lo, &j.hi);
@@ -461,6 +535,8 @@ extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_
   try {
     for (size_t s = 0; s < S; s++) th.emplace_back(shard_gather, &jobs[s]);
   } catch (...) {
+    /* the shards that did start are waiting for the ones that never will: stand in for those, with a no */
+    for (size_t s = th.size(); s < S; s++) (void)sync.arrive(false);
     for (auto &x : th) x.join();
     return VS_ERR_NOMEM;
   }
@@ -473,6 +549,12 @@ extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_
     if (rc == VS_OK && jobs[s].rc != VS_OK) rc = jobs[s].rc;
   }
   if (max_compute_ms) *max_compute_ms = mc;
+  if (sync.aborted.load() && nd->transport == VS_NODE_TRANSPORT_RCCL) {
+    /* the communicators were aborted: the node is back on the peer transport (vs_node_set_transport makes new ones) */
+    vs_node_drop_rccl(nd);
+    nd->transport = VS_NODE_TRANSPORT_PEER;
+    nd->link = nd->base_link;
+  }
   return rc;
 }
 
