@@ -141,7 +141,8 @@ def test_which_fused_kernel_a_plan_takes(engine):
     fit the LDS: three (open phase | noise | filter) on a full grid of deep rings with glottal noise
     (BASELINE config 3), two where the rings hold barely a cycle (config 5's F0 sweep: a filter wavefront
     that waits for all of its lanes starves there), where there is no glottal noise (config 2's shape),
-    and where every wavefront has a SIMD of its own (config 4's shard)."""
+    and three again on half-filled chips with glottal noise (config 4's shard: the filter wavefront alone on its
+    SIMD, open phase and noise together on the next; a 16384-utterance chunk: a SIMD per wavefront)."""
     def kernel(cfg, n):
         specs, fs, dur, _ = configs.config_specs(cfg, n)
         lanes, d = vs.lanes_from_specs(specs)
@@ -152,8 +153,9 @@ def test_which_fused_kernel_a_plan_takes(engine):
     assert kernel(3, 65536) == "vs_synth_ws_kernel<0, true, 3>"
     assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 2>"
     assert kernel(2, 65536) == "vs_synth_ws_kernel<0, true, 2>"
-    assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 2>"
-    assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 2>"   # a chunk of the delivery pipelines
+    assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 3>"
+    assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 3>"   # a chunk of the delivery pipelines
+    assert kernel(2, 1024) == "vs_synth_ws_kernel<0, true, 2>"
 
 
 def test_mixed_batch_every_option_combination(engine):

@@ -15,6 +15,8 @@ def main():
     print(label)
     lanes, d = vs.lanes_from_specs(specs); ns = vs.num_samples(fs, d)
     eng = vs.Engine(0); lib = vs.load()
+    if len(sys.argv) > 3 and sys.argv[3] == "fma":
+        eng.set_arith(vs.VS_ARITH_FMA); print("VS_ARITH_FMA")
     lib.vs_plan_set_diag.restype = C.c_int; lib.vs_plan_set_diag.argtypes = [C.c_void_p, C.c_void_p]
     plan = eng.plan(lanes, ns); grid = plan.info()["workgroups"]
     out = eng.dev_alloc(n * ns * 2); dg = eng.dev_alloc(grid * 16 * 8)

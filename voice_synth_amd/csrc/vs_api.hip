@@ -332,7 +332,7 @@ extern "C" void vs_cos_row(int T2, double *row)
  * up, which keeps both the rounds and the super-steps well attended; the policy table below
  * comes from replaying real period sequences through the scheduler.
  * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
-static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min)
+static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request = 0, double depth = 1.7)
 {
   const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (group_lanes * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
   /* one super-step + the longest cycle + the slots a trip may run past the cycle */
@@ -341,9 +341,10 @@ static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, in
   if (cap <= 0) cap = 288; /* (288 + 8) rows * 128 B = 37 KiB + cos rows + sync words: four workgroups per CU */
   cap = (cap / VS_SS) * VS_SS;
   if (cap > hard_limit) cap = hard_limit;
-  int want = ((VS_SS + (int)(1.7 * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
+  int want = ((VS_SS + (int)(depth * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
   if (want < 192) want = 192;
   int c = want < cap ? want : cap;
+  if (request > 0) c = cap; /* vs_tuning.ring_slots: the capacity itself, clamped to what fits */
   if (c < need) c = need;
   const double rho = (double)(c - VS_SS) / (double)tmax;
   int thr = 32;                 /* half the live lanes */
@@ -558,16 +559,45 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   unsigned wg_per_cu = (grid + cus - 1) / cus;
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
+  int ltab_entries = 0;
+  if (!filter_only) {
+    /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
+     * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
+    for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
+      int seen[VS_WAVE], nseen = 0, sum = 0;
+      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) {
+        bool dup = false;
+        for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
+        if (!dup) {
+          seen[nseen++] = dl[l].T2;
+          sum += (dl[l].T2 + 7) & ~7;
+        }
+      }
+      if (sum > ltab_entries) ltab_entries = sum;
+    }
+  }
   int cap = 0; /* default: four workgroups per CU */
-  if (wg_per_cu < 4) cap = (int)((VS_LDS_LIMIT / wg_per_cu - 4096) / (group_lanes * 2)) - VS_TRASH_ROWS;
+  if (wg_per_cu < 4) {
+    /* what the other residents of a group's LDS need: its cos rows (a batch of many periods stages up to 64 of them
+     * per wavefront) and the progress words of three roles; at least 4 KiB */
+    size_t others = (size_t)ltab_entries * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int) + 64;
+    if (others < 4096) others = 4096;
+    const long room = (long)(VS_LDS_LIMIT / wg_per_cu) - (long)others;
+    cap = (int)(room / (long)(group_lanes * 2)) - VS_TRASH_ROWS;
+    if (cap < VS_SS) cap = VS_SS; /* the policy lifts it to what the longest cycle needs, or refuses */
+  }
   if (tune.ring_slots > 0) cap = tune.ring_slots;
   int slots = 0, ready_min = 32;
-  int ltab_entries = 0;
   size_t lds_bytes = 0;
-  int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2;
+  int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2, ws_layout = VS_WS_LAYOUT_ROLE_MAJOR;
   bool all_deep = true; /* every group's ring holds 1.65 of its longest cycles or more (see the thresholds below) */
   if (!filter_only) {
-    int rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min);
+    /* Half-filled chips (at most two groups per CU) have LDS to spare: rings of 2.4 of the longest cycle instead of
+     * 1.7.  With a SIMD per wavefront nobody fills the gaps a starved filter wavefront leaves, and a deeper ring is what
+     * keeps it fed while rounds wait for (nearly) all lanes (config 4's shard, same box: two roles 5.2 / 4.07 ms -> 5.1 /
+     * 3.66 ms with 576 slots instead of 408; three roles 4.87 / 4.08 -> 4.80 / 3.40, profiles/r04_config4_roles.txt). */
+    const double depth = (wg_per_cu <= 2 && group_lanes == VS_WAVE) ? 2.4 : 1.7;
+    int rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min, tune.ring_slots, depth);
     if (rc != VS_OK) return rc;
     /* Super-step threshold, per 64-utterance group, from how many of the group's longest cycles
      * its ring holds (rho): a group whose ring holds barely one cycle cannot wait for all of its
@@ -594,20 +624,6 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       for (size_t l = w0; l < n_lanes && l < w0 + G; l++) dl[l].ready_min = thr;
     }
     ready_min = tune.ready_min > 0 ? tune.ready_min : 0; /* 0: the groups' own thresholds */
-    /* cos rows staged per wavefront: the distinct T2 among its 64 lanes, each row rounded up to
-     * a multiple of 8 (vs_stage_cos_rows), worst wavefront */
-    for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
-      int seen[VS_WAVE], nseen = 0, sum = 0;
-      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) {
-        bool dup = false;
-        for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
-        if (!dup) {
-          seen[nseen++] = dl[l].T2;
-          sum += (dl[l].T2 + 7) & ~7;
-        }
-      }
-      if (sum > ltab_entries) ltab_entries = sum;
-    }
     /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
     lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
     if (lds_bytes > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
@@ -633,9 +649,19 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * roles, profiles/r03_kernel_experiments.txt) */
       if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && all_deep && (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT)
         ws_roles = 3;
+      /* Half-filled chips (one or two groups per workgroup: BASELINE config 4's shard, the 16384-utterance chunks
+       * of the pipelines): the lone filter wavefront is the bound and the one generator wavefront next door takes
+       * three quarters of its time (4.65 against 3.52 ms alone, profiles/r04_config4_roles.txt) -- in VS_ARITH_FMA the
+       * generator IS the bound.  Three roles with the filter wavefront ALONE on its SIMD and the open-phase and the
+       * noise wavefront together on the next one (VS_WS_LAYOUT_SPREAD_2X3; with one group per workgroup the three
+       * wavefronts have a SIMD each anyway): the generator's work takes 1.84 ms that way.  The role-major layout
+       * of two groups would put the open-phase wavefront on the FILTER's SIMD (6.4 ms). */
+      if (wave_specialised && ws_pairs <= 2 && 2 * noisy >= n_lanes && all_deep && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)
+        ws_roles = 3;
       if (tune.ws_roles == 2) ws_roles = 2;
       if (tune.ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
       if (ws_roles == 3) ws_pair_bytes = bytes3;
+      if (ws_roles == 3 && ws_pairs == 2) ws_layout = VS_WS_LAYOUT_SPREAD_2X3;
     }
   }
 
@@ -659,6 +685,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
+  p->ws_layout = ws_layout;
   p->ws_shared_simd = (wave_specialised && grid > 2u * cus) ? 1 : 0;
   p->group_lanes = group_lanes;
   p->ws_pair_bytes = ws_pair_bytes;
@@ -837,6 +864,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;
   a.ws_roles = p->ws_roles;
+  a.ws_layout = p->ws_layout;
   a.group_lanes = p->group_lanes;
   a.ws_pair_bytes = p->ws_pair_bytes;
   /* a generator round starts when gen_min/64 of the lanes that still need cycles have room -- or at
@@ -846,6 +874,13 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
    * profiles/r03_kernel_experiments.txt): it waits for everybody unless a lane is nearly dry. */
   a.gen_min = p->tuning.gen_min > 0 ? p->tuning.gen_min : (p->ws_roles == 3 ? 64 : (p->ws_pairs == 4 ? 32 : 16));
   a.gen_low = p->tuning.gen_low > 0 ? p->tuning.gen_low : (p->ws_roles == 3 ? 32 : 2 * VS_SS);
+  /* three roles on a half-filled chip (the filter wavefront alone on its SIMD, deep rings): rounds for three quarters
+   * of the lanes, and at once for a lane that is down to 144 samples -- its filter's SIMD idles while it waits
+   * (sweep: profiles/r04_config4_roles.txt) */
+  if (p->ws_roles == 3 && p->ws_pairs <= 2) {
+    if (p->tuning.gen_min <= 0) a.gen_min = 48;
+    if (p->tuning.gen_low <= 0) a.gen_low = 144;
+  }
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;
   a.ws_filter_prio = p->tuning.ws_filter_prio == 0 ? 3 : (p->tuning.ws_filter_prio < 0 ? 0 : p->tuning.ws_filter_prio);

@@ -87,7 +87,18 @@ typedef struct VsKernelArgs {
   unsigned long long *diag; /* VS_DIAG builds only: per-wavefront cycle counters [grid][8] */
   int16_t *sink;       /* one row of n_samples + 32 samples nobody reads: where the lanes beyond n_lanes of the last group store (wave-specialised kernels) */
   const double *awide; /* wide plans (a coefficient set of 23..40 taps): A[1..40] per lane record, zeros behind its order */
+  int ws_layout;       /* wave-specialised kernels, how a workgroup's wavefronts map to roles: VS_WS_LAYOUT_* */
 } VsKernelArgs;
+
+/* Wavefronts of a workgroup are dealt to the CU's four SIMDs cyclically (wavefront w runs on SIMD w % 4).
+ *   ROLE_MAJOR  role = w / groups, group = w % groups: with four groups per workgroup the two or three wavefronts
+ *               of ONE group share a SIMD (full grids); with one or two groups every wavefront has a SIMD of its own.
+ *   SPREAD_2X3  two groups x three roles in EIGHT wavefronts, F0 O0 F1 O1 -- N0 -- N1 (two of them leave at once):
+ *               SIMDs 0 and 2 host a filter wavefront ALONE, SIMDs 1 and 3 the open-phase and the noise wavefront of
+ *               one group -- half-filled chips (BASELINE config 4's shard), where the lone filter wavefront is the
+ *               bound and the generator's work, cut in two, finishes well inside its shadow. */
+#define VS_WS_LAYOUT_ROLE_MAJOR 0
+#define VS_WS_LAYOUT_SPREAD_2X3 1
 
 #define VS_WIDE_ORDER 40 /* == VS_MAX_ORDER of voice_synth.h */
 #define VS_WIDE_SS 48    /* register window and super-step of the wide filter kernel (>= VS_WIDE_ORDER + 1, multiple of 8) */

@@ -64,6 +64,7 @@ struct vs_plan {
   int wave_specialised;
   int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
   int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */
+  int ws_layout;     /* VS_WS_LAYOUT_* (VsKernelArgs.ws_layout) */
   int ws_shared_simd; /* the wavefronts of a group share a SIMD (grids beyond two groups per CU) */
   int group_lanes;   /* utterances per wavefront: VS_WAVE, or VS_NARROW_LANES for periods beyond the 64-column ring */
   int ws_pair_bytes; /* LDS bytes of one pair */

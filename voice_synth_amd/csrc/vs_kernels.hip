@@ -639,10 +639,19 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
 {
   extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
 
-  const int ngroups = (int)blockDim.x / (ROLES * VS_WAVE);
   const int widx = (int)threadIdx.x >> 6;
-  const int role = widx / ngroups;
-  const int slot = widx - role * ngroups;
+  int ngroups, role, slot;
+  if (ROLES == 3 && args.ws_layout == VS_WS_LAYOUT_SPREAD_2X3) {
+    /* eight wavefronts: F0 O0 F1 O1 -- N0 -- N1 (vs_device.h); role -1 = nothing to do */
+    const int simd = widx & 3, second = widx >> 2;
+    ngroups = 2;
+    slot = simd >> 1;
+    role = (simd & 1) ? (second ? 1 : 0) : (second ? -1 : 2);
+  } else {
+    ngroups = (int)blockDim.x / (ROLES * VS_WAVE);
+    role = widx / ngroups;
+    slot = widx - role * ngroups;
+  }
   VsGroup g;
   g.lane = (int)threadIdx.x & (VS_WAVE - 1);
   g.group = (long)blockIdx.x * (long)ngroups + slot;
@@ -669,6 +678,7 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
     }
   }
   __syncthreads();
+  if (role < 0) return; /* the two spare wavefronts of the spread layout */
 
 #ifdef VS_TIMING_GENERATOR_ONLY
   if (role == ROLES - 1) return;
@@ -1065,6 +1075,10 @@ extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_sp
     /* lds_bytes arrives as the bytes of ONE group (ring + cos rows + progress words); args->ws_pairs
      * groups share a workgroup, args->ws_roles wavefronts serve each */
     block = (unsigned)args->ws_roles * VS_WAVE * (unsigned)args->ws_pairs;
+    if (three && args->ws_layout == VS_WS_LAYOUT_SPREAD_2X3) {
+      if (args->ws_pairs != 2) return hipErrorInvalidValue;
+      block = 8 * VS_WAVE;
+    }
     lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
   } else
