@@ -89,7 +89,7 @@ run_step() {
       timeout -k 10 200 python tools/diag_ws.py "$@" | tee gpurun_out/diag_ws.txt ;;
     full)
       # the round's evidence pass: tests, smoke, kernel trace, traffic and SQ counters (exact + fma), bench
-      local tag=${1:-r03}
+      local tag=${1:-r04}
       run_step test || return 1
       run_step smoke || return 1
       run_step prof ${tag}_bench --no-cpu-baseline || return 1
