@@ -27,7 +27,9 @@
  * from HBM -- the un-fused path), vs_selftest_kernel (the arithmetic shortcuts against their
  * literal forms, on the device).
  *
- * No MFMA: the path is a scalar recurrence per utterance, not a contraction.
+ * No MFMA: the path is a scalar recurrence per utterance, not a contraction -- and the block form that would make
+ * it one (16 samples x 16 utterances per tile, 40 multiply-adds per sample instead of 22) loses on gfx950, whose
+ * fp64 matrix instructions run at the vector rate on the vector issue port (tools/ubench/ubench6.hip).
  *
  * Arithmetic contract: this file is compiled with -ffp-contract=off.  VS_ARITH_EXACT keeps
  * the reference's rounding sequence operation by operation (mul, then sub, j = 1..22), so the
@@ -238,11 +240,9 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  * one job, coupled through the LDS ring and a few per-lane progress words.  This is what the fused
  * kind launches by default (vs_plan_create):
  *
- *   two roles (generator | filter) -- grids that leave at least half of the chip's SIMDs empty
- *     (e.g. BASELINE config 4 sharded over 8 GPUs: 32768 utterances per GPU = 512 groups on 1024
- *     SIMDs): one or two pairs per workgroup, every wavefront has a SIMD of its own and a launch
- *     takes max(generator, filter) instead of their sum (1.35-1.6x); and full grids that do not suit
- *     the third role (no glottal noise; rings of barely one cycle: vs_plan_create_impl);
+ *   two roles (generator | filter) -- whatever does not suit the third role (no glottal noise; rings of
+ *     barely one cycle: vs_plan_create_impl).  On grids that leave at least half of the chip's SIMDs empty
+ *     every wavefront has a SIMD of its own and a launch takes max(generator, filter) instead of their sum;
  *
  *   three roles (open phase | noise | filter) -- full grids over deep rings (BASELINE config 3: 1024
  *     groups on 1024 SIMDs): four groups per 768-thread workgroup, one workgroup per CU, wavefronts laid out
@@ -255,6 +255,10 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  *     filter sleeps.  Two generator wavefronts side by side run at 5.25 and 11 cycles per
  *     instruction (ubench4.hip), i.e. that part goes ~1.5x faster when the generator's work is cut
  *     in two: jitter / shimmer / both flanks here, the closed phase's noise there.
+ *     Half-filled chips with glottal noise (BASELINE config 4 sharded over 8 GPUs: 512 groups on 1024 SIMDs; the
+ *     16384-utterance chunks of the pipelines) take three roles too, laid out so that the filter wavefront -- the
+ *     bound in exact arithmetic -- has a SIMD to itself and the two generator wavefronts share the next one
+ *     (VS_WS_LAYOUT_SPREAD_2X3, vs_device.h; one group per workgroup: a SIMD per wavefront), over rings of 2.4 cycles.
  *
  * Hand-off (workgroup scope, LDS only), per lane l:
  *   gpub[l] = samples of l that are complete in the ring     (written by the generator / by the noise wavefront)
