@@ -1,4 +1,5 @@
-# Top-level build: the product library + drop-in CLIs (hipcc, gfx950 only) and the oracle.
+# Top-level build: the product library + drop-in CLIs (gfx950 only) and the oracle.
+# Host code is C (gcc, the HIP runtime through its C API); hipcc compiles the kernels and links.
 #
 #   make            -> voice_synth_amd/lib/libvoicesynth.so, voice_synth_amd/bin/{flowgen_shimmer,vowel}
 #   make oracle     -> oracle/liboracle.so and, when /root/reference exists, oracle/_ref/*
@@ -19,6 +20,8 @@ BINDIR  := $(PKG)/bin
 KERNEL_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_dev_primitives.h $(CSRC)/vs_dev_generator.h $(CSRC)/vs_dev_filter.h include/voice_synth.h
 HIPFLAGS := -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
 CFLAGS   := -O2 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Wno-unused-parameter
+HOSTFLAGS := -std=gnu11 $(CFLAGS) -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
+HOST_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
 
 LIB := $(LIBDIR)/libvoicesynth.so
 
@@ -37,14 +40,15 @@ $(CSRC)/vs_kernels.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 $(CSRC)/vs_kernels_narrow.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DVS_GROUP_LANES=16 -c -o $@ $<
 
-$(CSRC)/vs_api.o: $(CSRC)/vs_api.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+# the host side of the library: plain C against the HIP runtime's C API
+$(CSRC)/vs_api.o: $(CSRC)/vs_api.c $(HOST_HDRS)
+	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.c $(HOST_HDRS)
+	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(CSRC)/vs_node.o: $(CSRC)/vs_node.hip $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(CSRC)/vs_node.o: $(CSRC)/vs_node.c $(HOST_HDRS)
+	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
 $(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl

@@ -178,7 +178,7 @@ def config_specs(index, n_lanes=None, lane0=0, seed0=1):
 
 def shard_range(n_lanes, rank, world):
     """Contiguous lane block [lo, hi) of `rank` of `world`; blocks differ by at most one lane.  The same cut
-    as vs_node_shard_range() in csrc/vs_node.hip (tests/test_gpu_node.py holds the two together)."""
+    as vs_node_shard_range() in csrc/vs_node.c (tests/test_gpu_node.py holds the two together)."""
     base, rem = divmod(int(n_lanes), int(world))
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)

@@ -1,7 +1,7 @@
 /*
- * vs_api.hip -- host side of the C ABI (include/voice_synth.h): device context, plans
- * (parameter expansion + cos tables + upload) and launches.  C++ only as far as hipcc wants
- * it; the ABI is plain C.
+ * vs_api.c -- host side of the C ABI (include/voice_synth.h): device context, plans
+ * (parameter expansion + cos tables + upload) and launches.  C11 + pthreads, the HIP runtime through
+ * its C API; the kernels are launched through the extern "C" launchers of vs_kernels.hip.
  *
  * Everything that is a pure function of a lane's parameters is evaluated HERE, on the host,
  * with the reference's operand types, so the device never evaluates a transcendental:
@@ -13,36 +13,27 @@
  *   (float)1.8*amp, (float)0.2*amp               flowgen_shimmer.c:306
  * This translation unit is compiled with -ffp-contract=off.
  */
-#include <hip/hip_runtime.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <map>
-#include <new>
-#include <thread>
-#include <vector>
-
-#include "../../include/voice_synth.h"
-#include "vs_device.h"
-
-extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
-extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
-extern "C" hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream);
-extern "C" hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1,
-                                       const VsKernelArgs *args, unsigned grid, size_t lds_bytes,
-                                       hipStream_t stream);
+#include <time.h>
+#include <unistd.h>
 
 #include "vs_internal.h"
 
-extern "C" int vs_ctx_create(int device, vs_ctx **out)
+double vs_now_ms(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
+
+int vs_ctx_create(int device, vs_ctx **out)
 {
   if (!out) return VS_ERR_ARG;
-  *out = nullptr;
+  *out = NULL;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return VS_ERR_NODEVICE;
   if (device < 0 || device >= count) return VS_ERR_NODEVICE;
@@ -50,14 +41,14 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return VS_ERR_NODEVICE;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VS_ERR_NODEVICE; /* code object is gfx950 only */
   if (hipSetDevice(device) != hipSuccess) return VS_ERR_NODEVICE;
-  vs_ctx *ctx = new (std::nothrow) vs_ctx();
+  vs_ctx *ctx = (vs_ctx *)calloc(1, sizeof(vs_ctx));
   if (!ctx) return VS_ERR_NOMEM;
   ctx->device = device;
   ctx->arith = VS_ARITH_EXACT;
-  ctx->stream = nullptr;
-  ctx->upload = nullptr;
+  ctx->stream = NULL;
+  ctx->upload = NULL;
   ctx->last_hip_error = 0;
-  snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+  snprintf(ctx->name, sizeof(ctx->name), "%.80s (%.40s)", prop.name, prop.gcnArchName);
   ctx->cu_count = prop.multiProcessorCount;
   memset(&ctx->tuning, 0, sizeof(ctx->tuning));
   memset(&ctx->pool, 0, sizeof(ctx->pool));
@@ -66,20 +57,20 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
    * (profiles/r04_plan_cost.txt).  Paid HERE, once per context, so that the first vs_plan_create of a
    * process costs what every later one costs. */
   {
-    void *scratch = nullptr;
+    void *scratch = NULL;
     const size_t warm_bytes = 1u << 20;
     void *host = malloc(warm_bytes);
     hipError_t e = host ? hipMalloc(&scratch, warm_bytes) : hipErrorOutOfMemory;
     if (e == hipSuccess) {
       memset(host, 0, warm_bytes);
-      e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, nullptr);
-      if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, nullptr);
-      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, NULL);
+      if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, NULL);
+      if (e == hipSuccess) e = hipStreamSynchronize(NULL);
       (void)hipFree(scratch);
     }
     free(host);
     if (e != hipSuccess) {
-      delete ctx;
+      free(ctx);
       return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
     }
   }
@@ -92,16 +83,16 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
       vs_tuning t;
       memset(&t, 0, sizeof(t));
       const char *v;
-      if ((v = getenv("VS_KERNEL")) != nullptr) t.kernel = strcmp(v, "ws") == 0 ? VS_KERNEL_WS : (strcmp(v, "single") == 0 ? VS_KERNEL_SINGLE : VS_KERNEL_AUTO);
-      if ((v = getenv("VS_RING_SLOTS")) != nullptr) t.ring_slots = atoi(v);
-      if ((v = getenv("VS_READY_MIN")) != nullptr) t.ready_min = atoi(v);
-      if ((v = getenv("VS_WS_PAIRS")) != nullptr) t.ws_pairs = atoi(v);
-      if ((v = getenv("VS_WS_ROLES")) != nullptr) t.ws_roles = atoi(v);
-      if ((v = getenv("VS_GEN_LOW")) != nullptr) t.gen_low = atoi(v);
-      if ((v = getenv("VS_GEN_MIN")) != nullptr) t.gen_min = atoi(v);
-      if ((v = getenv("VS_WS_PRIO")) != nullptr) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
+      if ((v = getenv("VS_KERNEL")) != NULL) t.kernel = strcmp(v, "ws") == 0 ? VS_KERNEL_WS : (strcmp(v, "single") == 0 ? VS_KERNEL_SINGLE : VS_KERNEL_AUTO);
+      if ((v = getenv("VS_RING_SLOTS")) != NULL) t.ring_slots = atoi(v);
+      if ((v = getenv("VS_READY_MIN")) != NULL) t.ready_min = atoi(v);
+      if ((v = getenv("VS_WS_PAIRS")) != NULL) t.ws_pairs = atoi(v);
+      if ((v = getenv("VS_WS_ROLES")) != NULL) t.ws_roles = atoi(v);
+      if ((v = getenv("VS_GEN_LOW")) != NULL) t.gen_low = atoi(v);
+      if ((v = getenv("VS_GEN_MIN")) != NULL) t.gen_min = atoi(v);
+      if ((v = getenv("VS_WS_PRIO")) != NULL) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
       if (vs_ctx_set_tuning(ctx, &t) != VS_OK) {
-        delete ctx;
+        free(ctx);
         return VS_ERR_ARG;
       }
     }
@@ -110,7 +101,7 @@ extern "C" int vs_ctx_create(int device, vs_ctx **out)
   return VS_OK;
 }
 
-extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
+int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
 {
   if (!ctx) return VS_ERR_ARG;
   if (!t) {
@@ -133,30 +124,30 @@ extern "C" int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   return VS_OK;
 }
 
-extern "C" void vs_ctx_destroy(vs_ctx *ctx)
+void vs_ctx_destroy(vs_ctx *ctx)
 {
   if (!ctx) return;
   vs_pool_release(ctx);
-  delete ctx;
+  free(ctx);
 }
 
-extern "C" int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream)
+int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream)
 {
   if (!ctx) return VS_ERR_ARG;
   ctx->stream = (hipStream_t)hip_stream;
   return VS_OK;
 }
 
-extern "C" int vs_ctx_set_arith(vs_ctx *ctx, int arith)
+int vs_ctx_set_arith(vs_ctx *ctx, int arith)
 {
   if (!ctx || (arith != VS_ARITH_EXACT && arith != VS_ARITH_FMA)) return VS_ERR_ARG;
   ctx->arith = arith;
   return VS_OK;
 }
 
-extern "C" int vs_ctx_last_hip_error(const vs_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
+int vs_ctx_last_hip_error(const vs_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
 
-extern "C" int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count)
+int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count)
 {
   if (!ctx) return VS_ERR_ARG;
   if (name && name_len) snprintf(name, name_len, "%s", ctx->name);
@@ -164,7 +155,7 @@ extern "C" int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len
   return VS_OK;
 }
 
-extern "C" int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len)
+int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len)
 {
   if (!ctx || !bus_id || len < 16) return VS_ERR_ARG;
   bus_id[0] = '\0';
@@ -173,7 +164,7 @@ extern "C" int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len)
   return VS_OK;
 }
 
-extern "C" int vs_ctx_synchronize(vs_ctx *ctx)
+int vs_ctx_synchronize(vs_ctx *ctx)
 {
   if (!ctx) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
@@ -181,10 +172,10 @@ extern "C" int vs_ctx_synchronize(vs_ctx *ctx)
   return VS_OK;
 }
 
-extern "C" int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
+int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
 {
   if (!ctx) return VS_ERR_ARG;
-  unsigned long long *d = nullptr, h[VS_SELFTEST_COUNTERS] = {0};
+  unsigned long long *d = NULL, h[VS_SELFTEST_COUNTERS] = {0};
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipMalloc((void **)&d, sizeof(h)));
   hipError_t e = hipMemsetAsync(d, 0, sizeof(h), ctx->stream);
@@ -204,21 +195,21 @@ extern "C" int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
   return any ? VS_ERR_INTERNAL : VS_OK;
 }
 
-extern "C" int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr)
+int vs_dev_alloc(vs_ctx *ctx, size_t bytes, void **ptr)
 {
   if (!ctx || !ptr) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipMalloc(ptr, bytes ? bytes : 1));
   return VS_OK;
 }
-extern "C" int vs_dev_free(vs_ctx *ctx, void *ptr)
+int vs_dev_free(vs_ctx *ctx, void *ptr)
 {
   if (!ctx) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipFree(ptr));
   return VS_OK;
 }
-extern "C" int vs_dev_upload(vs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+int vs_dev_upload(vs_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
   if (!ctx) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
@@ -226,7 +217,7 @@ extern "C" int vs_dev_upload(vs_ctx *ctx, void *dst_dev, const void *src_host, s
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return VS_OK;
 }
-extern "C" int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
 {
   if (!ctx) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
@@ -255,7 +246,7 @@ static bool vs_lane_is_wide(const vs_lane *lane)
   return lane->vowel == VS_VOWEL_CUSTOM && lane->order > VS_ORDER;
 }
 
-extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
+int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 {
   int rc = vs_lane_validate(lane);
   if (rc != VS_OK) return rc;
@@ -319,7 +310,7 @@ extern "C" int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 
 /* cos(PI*k/T2) with PI the reference's macro 4.0*atan(1.0) (flowgen_shimmer.c:39), which
  * expands textually: PI*i/T2 == ((4.0*atan(1.0))*i)/T2 */
-extern "C" void vs_cos_row(int T2, double *row)
+void vs_cos_row(int T2, double *row)
 {
   for (int k = 0; k < T2; k++) row[k] = cos(4.0 * atan(1.0) * k / T2);
 }
@@ -332,7 +323,7 @@ extern "C" void vs_cos_row(int T2, double *row)
  * up, which keeps both the rounds and the super-steps well attended; the policy table below
  * comes from replaying real period sequences through the scheduler.
  * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
-static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request = 0, double depth = 1.7)
+static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request, double depth)
 {
   const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (group_lanes * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
   /* one super-step + the longest cycle + the slots a trip may run past the cycle */
@@ -357,17 +348,17 @@ static int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, in
 }
 
 /* a ring of 64 columns (one utterance per lane of a wavefront) */
-extern "C" int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
+int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
 {
-  return vs_ring_policy_for(VS_WAVE, tmax, cap, slots, ready_min);
+  return vs_ring_policy_for(VS_WAVE, tmax, cap, slots, ready_min, 0, 1.7);
 }
 
 /* Ring capacity for periods up to tmax: the 64-column ring if it can take them, else the narrow one
  * (VS_NARROW_LANES columns, four times the slots in the same LDS). */
-extern "C" int vs_ring_slots_for(int tmax, int *slots)
+int vs_ring_slots_for(int tmax, int *slots)
 {
-  int rc = vs_ring_policy_for(VS_WAVE, tmax, 0, slots, nullptr);
-  if (rc == VS_ERR_UNSUPPORTED) rc = vs_ring_policy_for(VS_NARROW_LANES, tmax, 0, slots, nullptr);
+  int rc = vs_ring_policy_for(VS_WAVE, tmax, 0, slots, NULL, 0, 1.7);
+  if (rc == VS_ERR_UNSUPPORTED) rc = vs_ring_policy_for(VS_NARROW_LANES, tmax, 0, slots, NULL, 0, 1.7);
   return rc;
 }
 
@@ -409,65 +400,148 @@ static int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
   return VS_OK;
 }
 
+/* ---- pieces of vs_plan_create_impl ---- */
+
+/* expansion of the lane records: independent per lane, so large batches are cut over a few host
+ * threads (65536 lanes: 38 ms on one core, the kernel itself takes under 3 ms) */
+typedef struct ExpandJob {
+  const vs_lane *lanes;
+  VsDevLane *dl;
+  size_t lo, hi;
+  int filter_only;
+  int rc;          /* first failure in [lo, hi) */
+  size_t bad;      /* ... and the lane it belongs to */
+} ExpandJob;
+
+static void *expand_range(void *arg)
+{
+  ExpandJob *j = (ExpandJob *)arg;
+  j->rc = VS_OK;
+  for (size_t l = j->lo; l < j->hi; l++) {
+    const int rc = j->filter_only ? vs_expand_filter_lane(&j->lanes[l], (int32_t)l, &j->dl[l])
+                                  : vs_expand_lane(&j->lanes[l], (int32_t)l, &j->dl[l]);
+    if (rc != VS_OK) {
+      j->rc = rc;
+      j->bad = l;
+      break;
+    }
+  }
+  return NULL;
+}
+
+static int expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only)
+{
+  long nt = 1;
+  if (n_lanes >= 8192) {
+    nt = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt > 8) nt = 8;
+    if (nt < 1) nt = 1;
+  }
+  ExpandJob jobs[8];
+  pthread_t th[8];
+  const size_t per = (n_lanes + (size_t)nt - 1) / (size_t)nt;
+  int started = 0, n_jobs = 0;
+  for (long t = 0; t < nt; t++) {
+    const size_t lo = (size_t)t * per, hi = (lo + per < n_lanes) ? lo + per : n_lanes;
+    if (lo >= hi) break;
+    jobs[n_jobs].lanes = lanes;
+    jobs[n_jobs].dl = dl;
+    jobs[n_jobs].lo = lo;
+    jobs[n_jobs].hi = hi;
+    jobs[n_jobs].filter_only = filter_only;
+    jobs[n_jobs].rc = VS_OK;
+    jobs[n_jobs].bad = 0;
+    n_jobs++;
+  }
+  /* the last range runs on this thread; a thread that cannot be started is run here too */
+  for (int t = 0; t + 1 < n_jobs; t++) {
+    if (pthread_create(&th[t], NULL, expand_range, &jobs[t]) != 0) break;
+    started++;
+  }
+  for (int t = started; t < n_jobs; t++) expand_range(&jobs[t]);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  for (int t = 0; t < n_jobs; t++) /* the failure of the lowest lane: the same answer whatever the thread count */
+    if (jobs[t].rc != VS_OK) return jobs[t].rc;
+  return VS_OK;
+}
+
+/* Wavefronts are formed from lanes with similar periods: stable order by (P, T2, flags).  A merge sort
+ * of lane indices (stable by construction), then one pass that moves the records. */
+static int lane_before(const VsDevLane *a, const VsDevLane *b)
+{
+  if (a->P != b->P) return a->P < b->P;
+  if (a->T2 != b->T2) return a->T2 < b->T2;
+  return a->flags < b->flags;
+}
+
+static int sort_lanes(VsDevLane **pdl, size_t n)
+{
+  VsDevLane *dl = *pdl;
+  uint32_t *idx = (uint32_t *)malloc(n * sizeof(uint32_t)), *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
+  VsDevLane *sorted = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+  if (!idx || !tmp || !sorted) {
+    free(idx);
+    free(tmp);
+    free(sorted);
+    return VS_ERR_NOMEM;
+  }
+  for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+  for (size_t w = 1; w < n; w *= 2) {
+    for (size_t lo = 0; lo < n; lo += 2 * w) {
+      const size_t mid = (lo + w < n) ? lo + w : n, hi = (lo + 2 * w < n) ? lo + 2 * w : n;
+      size_t a = lo, b = mid, o = lo;
+      while (a < mid && b < hi) tmp[o++] = lane_before(&dl[idx[b]], &dl[idx[a]]) ? idx[b++] : idx[a++]; /* ties: the left run first */
+      while (a < mid) tmp[o++] = idx[a++];
+      while (b < hi) tmp[o++] = idx[b++];
+    }
+    uint32_t *sw = idx;
+    idx = tmp;
+    tmp = sw;
+  }
+  for (size_t i = 0; i < n; i++) sorted[i] = dl[idx[i]];
+  free(idx);
+  free(tmp);
+  free(dl);
+  *pdl = sorted;
+  return VS_OK;
+}
+
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                         int mode, vs_plan **out)
 {
   const int filter_only = (mode & VS_PLAN_FILTER_ONLY) ? 1 : 0;
   if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
-  *out = nullptr;
-  const vs_tuning &tune = ctx->tuning;
-  std::vector<VsDevLane> dl;
-  std::vector<double> costab;
-  std::map<int, int> row_of_T2;
-  try {
-    dl.resize(n_lanes);
-  } catch (...) {
-    return VS_ERR_NOMEM;
-  }
-  const auto t_host0 = std::chrono::steady_clock::now();
-  /* expansion of the lane records: independent per lane, so large batches are cut over a few
-   * host threads (65536 lanes: 38 ms on one core, the kernel itself takes 3.5 ms) */
-  {
-    unsigned nt = 1;
-    if (n_lanes >= 8192) {
-      nt = std::thread::hardware_concurrency();
-      if (nt > 8) nt = 8;
-      if (nt < 1) nt = 1;
-    }
-    std::atomic<int> first_rc(VS_OK);
-    auto work = [&](size_t lo, size_t hi) {
-      for (size_t l = lo; l < hi; l++) {
-        const int rc = filter_only ? vs_expand_filter_lane(&lanes[l], (int32_t)l, &dl[l])
-                                   : vs_expand_lane(&lanes[l], (int32_t)l, &dl[l]);
-        if (rc != VS_OK) {
-          int expect = VS_OK;
-          first_rc.compare_exchange_strong(expect, rc);
-          return;
-        }
-      }
-    };
-    if (nt == 1) {
-      work(0, n_lanes);
-    } else {
-      std::vector<std::thread> th;
-      const size_t per = (n_lanes + nt - 1) / nt;
-      try {
-        for (unsigned t = 0; t < nt; t++) {
-          const size_t lo = (size_t)t * per, hi = std::min(n_lanes, lo + per);
-          if (lo < hi) th.emplace_back(work, lo, hi);
-        }
-      } catch (...) {
-        for (auto &x : th) x.join();
-        return VS_ERR_NOMEM;
-      }
-      for (auto &x : th) x.join();
-    }
-    if (first_rc.load() != VS_OK) return first_rc.load();
-  }
+  *out = NULL;
+  const vs_tuning *tune = &ctx->tuning;
+  int rc = VS_OK;
+  /* host memory of this call, released at `done` */
+  VsDevLane *dl = (VsDevLane *)malloc(n_lanes * sizeof(VsDevLane));
+  double *costab = NULL;   /* the cos rows, one per distinct T2 */
+  size_t costab_len = 0, costab_cap = 0;
+  int *row_of_T2 = NULL;   /* first entry of the row of T2 in costab, -1: not built yet */
+  double *awide = NULL;    /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
+  vs_plan *p = NULL;
+  if (!dl) return VS_ERR_NOMEM;
+  const double t_host0 = vs_now_ms();
+  rc = expand_all(lanes, dl, n_lanes, filter_only);
+  if (rc != VS_OK) goto done;
+
   int tmax = 1;
   int min_lframe = 0; /* shortest frame of the batch, once any lane asks for output noise */
   bool any_onoise = false;
+  {
+    int max_T2 = 0;
+    if (!filter_only)
+      for (size_t l = 0; l < n_lanes; l++)
+        if (dl[l].T2 > max_T2) max_T2 = dl[l].T2;
+    row_of_T2 = (int *)malloc(((size_t)max_T2 + 1) * sizeof(int));
+    if (!row_of_T2) {
+      rc = VS_ERR_NOMEM;
+      goto done;
+    }
+    for (int t = 0; t <= max_T2; t++) row_of_T2[t] = -1;
+  }
   for (size_t l = 0; l < n_lanes; l++) {
     /* every lane of a launch with output noise accumulates its frame powers, so the rows of the
      * power table must hold the lane with the MOST frames, whether it asks for noise or not */
@@ -475,16 +549,23 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (dl[l].Lframe > 0 && (min_lframe == 0 || dl[l].Lframe < min_lframe)) min_lframe = dl[l].Lframe;
     if (filter_only) continue;
     const int T2 = dl[l].T2;
-    std::map<int, int>::iterator it = row_of_T2.find(T2);
-    if (it == row_of_T2.end()) {
-      const int off = (int)costab.size();
-      costab.resize(costab.size() + (size_t)T2);
-      vs_cos_row(T2, &costab[off]);
-      row_of_T2[T2] = off;
-      dl[l].tab_off = off;
-    } else {
-      dl[l].tab_off = it->second;
+    if (row_of_T2[T2] < 0) {
+      if (costab_len + (size_t)T2 > costab_cap) {
+        size_t cap = costab_cap ? 2 * costab_cap : 1024;
+        while (cap < costab_len + (size_t)T2) cap *= 2;
+        double *grown = (double *)realloc(costab, cap * sizeof(double));
+        if (!grown) {
+          rc = VS_ERR_NOMEM;
+          goto done;
+        }
+        costab = grown;
+        costab_cap = cap;
+      }
+      vs_cos_row(T2, &costab[costab_len]);
+      row_of_T2[T2] = (int)costab_len;
+      costab_len += (size_t)T2;
     }
+    dl[l].tab_off = row_of_T2[T2];
     if (dl[l].tbound > tmax) tmax = dl[l].tbound;
   }
   bool pre1 = true;
@@ -492,7 +573,10 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   bool wide = false;
   for (size_t l = 0; l < n_lanes && !wide; l++) wide = vs_lane_is_wide(&lanes[l]);
   if (!any_onoise) min_lframe = 0;
-  if (any_onoise && min_lframe <= 0) return VS_ERR_UNSUPPORTED;
+  if (any_onoise && min_lframe <= 0) {
+    rc = VS_ERR_UNSUPPORTED;
+    goto done;
+  }
   /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its
    * longest lane and the cos rows of a wavefront are staged once per distinct T2, so a batch with
    * an F0 sweep (BASELINE config 5) is sorted by (P, T2, options) before it is cut into groups of
@@ -504,26 +588,15 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     for (size_t l = 1; l < n_lanes && !mixed; l++)
       mixed = dl[l].P != dl[0].P || dl[l].T2 != dl[0].T2 || dl[l].flags != dl[0].flags;
     if (mixed) {
-      std::stable_sort(dl.begin(), dl.end(), [](const VsDevLane &a, const VsDevLane &b) {
-        if (a.P != b.P) return a.P < b.P;
-        if (a.T2 != b.T2) return a.T2 < b.T2;
-        return a.flags < b.flags;
-      });
+      rc = sort_lanes(&dl, n_lanes);
+      if (rc != VS_OK) goto done;
     }
   }
   /* Launch shape.  A full chip is 4 x cu_count SIMDs.  The fused kind runs WAVE-SPECIALISED
-   * whenever it can: a generator wavefront and a filter wavefront per 64 utterances, coupled
-   * through the LDS ring (vs_synth_ws_kernel).
-   *  - up to half of the SIMDs' worth of groups (e.g. BASELINE config 4 sharded over 8 GPUs, 32768
-   *    utterances per GPU): every wavefront has a SIMD of its own and a launch takes
-   *    max(generator, filter) instead of their sum (1.35-1.45x);
-   *  - full grids (BASELINE config 3: 1024 groups on 1024 SIMDs): four pairs per 512-thread
-   *    workgroup, one workgroup per CU, laid out so that every SIMD hosts the generator and the
-   *    filter of one pair, the filter wavefront at raised priority.  One wavefront alone issues an
-   *    instruction every ~5.3 cycles; two on a SIMD fill each other's gaps (measured: 13 % faster
-   *    than one wavefront doing both jobs, profiles/r02_ws_full_grid_sweep.txt).
+   * whenever it can: two or three wavefronts per 64 utterances with one job each, coupled through
+   * the LDS ring (vs_synth_ws_kernel; which roles and which layout: below, and DESIGN.md section 4.2).
    * The one-wave kernel remains for the source-only and filter-only kinds, the per-cycle log, the
-   * vowel -n power sums, and rings too long for a pair to fit the LDS. */
+   * vowel -n power sums, and rings too long for a group to fit the LDS. */
   const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
   /* Utterances per wavefront: 64 -- unless the longest period of the batch does not fit a 64-column
    * ring (the reference takes any rate but an explicit 22050, flowgen_shimmer.c:535-540, and sizes
@@ -533,26 +606,24 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   int group_lanes = VS_WAVE;
   if (!filter_only) {
     int probe = 0;
-    if (vs_ring_policy_for(VS_WAVE, tmax, 0, &probe, nullptr) == VS_ERR_UNSUPPORTED) group_lanes = VS_NARROW_LANES;
+    if (vs_ring_policy_for(VS_WAVE, tmax, 0, &probe, NULL, 0, 1.7) == VS_ERR_UNSUPPORTED) group_lanes = VS_NARROW_LANES;
   }
   const size_t G = (size_t)group_lanes;
   const unsigned grid = (unsigned)((n_lanes + G - 1) / G);
   int wave_specialised = 1;
-  if (tune.kernel == VS_KERNEL_WS) wave_specialised = 1;
-  if (tune.kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
+  if (tune->kernel == VS_KERNEL_WS) wave_specialised = 1;
+  if (tune->kernel == VS_KERNEL_SINGLE) wave_specialised = 0;
   if (filter_only || wide || group_lanes != VS_WAVE) wave_specialised = 0;
-  /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
-  std::vector<double> awide;
   if (wide) {
-    try {
-      awide.resize(n_lanes * (size_t)VS_WIDE_ORDER);
-    } catch (...) {
-      return VS_ERR_NOMEM;
+    awide = (double *)malloc(n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
+    if (!awide) {
+      rc = VS_ERR_NOMEM;
+      goto done;
     }
     double A[VS_MAX_NCOEF];
     for (size_t l = 0; l < n_lanes; l++) {
-      const int rc = vs_lane_taps(&lanes[(size_t)dl[l].row], A);
-      if (rc != VS_OK) return rc;
+      rc = vs_lane_taps(&lanes[(size_t)dl[l].row], A);
+      if (rc != VS_OK) goto done;
       for (int j = 1; j <= VS_WIDE_ORDER; j++) awide[l * VS_WIDE_ORDER + (size_t)(j - 1)] = A[j];
     }
   }
@@ -586,7 +657,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     cap = (int)(room / (long)(group_lanes * 2)) - VS_TRASH_ROWS;
     if (cap < VS_SS) cap = VS_SS; /* the policy lifts it to what the longest cycle needs, or refuses */
   }
-  if (tune.ring_slots > 0) cap = tune.ring_slots;
+  if (tune->ring_slots > 0) cap = tune->ring_slots;
   int slots = 0, ready_min = 32;
   size_t lds_bytes = 0;
   int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2, ws_layout = VS_WS_LAYOUT_ROLE_MAJOR;
@@ -597,23 +668,22 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
      * keeps it fed while rounds wait for (nearly) all lanes (config 4's shard, same box: two roles 5.2 / 4.07 ms -> 5.1 /
      * 3.66 ms with 576 slots instead of 408; three roles 4.87 / 4.08 -> 4.80 / 3.40, profiles/r04_config4_roles.txt). */
     const double depth = (wg_per_cu <= 2 && group_lanes == VS_WAVE) ? 2.4 : 1.7;
-    int rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min, tune.ring_slots, depth);
-    if (rc != VS_OK) return rc;
+    rc = vs_ring_policy_for(group_lanes, tmax, cap, &slots, &ready_min, tune->ring_slots, depth);
+    if (rc != VS_OK) goto done;
     /* Super-step threshold, per 64-utterance group, from how many of the group's longest cycles
      * its ring holds (rho): a group whose ring holds barely one cycle cannot wait for all of its
      * lanes.  One-wave kernel: the table of vs_ring_policy (replayed period sequences).
      * Wave-specialised kernel, measured (profiles/README.md, r03_kernel_experiments.txt): over a deep
      * ring (rho >= 1.65: BASELINE configs 3 and 4) the filter wavefront waits for ALL of its lanes --
      * they then share one position, and the super-step loop runs without the copy of the window, the
-     * exec masks and the per-lane bounds that a wavefront of stragglers costs (config 4's shard, a SIMD
-     * per wavefront: 4.88 ms against 5.25 with super-steps from 62 %; in VS_ARITH_FMA, whose filter is
-     * no slower than the generator, 4.01 against 3.95 -- vs_launch lowers the threshold again there).
-     * Over shallower rings: three quarters of the lanes when generator and filter share a SIMD (the
-     * long periods of config 5's F0 sweep), 62 % when each has its own. */
+     * exec masks and the per-lane bounds that a wavefront of stragglers costs.  Over shallower rings:
+     * three quarters of the lanes when generator and filter share a SIMD (the long periods of config 5's
+     * F0 sweep), 62 % when each has its own. */
     const bool ws_shared_simd = wave_specialised && grid > 2u * cus;
     for (size_t w0 = 0; w0 < n_lanes; w0 += G) {
       int tb = 1;
-      for (size_t l = w0; l < n_lanes && l < w0 + G; l++) tb = std::max(tb, (int)dl[l].tbound);
+      for (size_t l = w0; l < n_lanes && l < w0 + G; l++)
+        if ((int)dl[l].tbound > tb) tb = (int)dl[l].tbound;
       const double rho = (double)(slots - VS_SS) / (double)tb;
       if (rho < 1.65) all_deep = false;
       int thr = 32;
@@ -623,18 +693,21 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       if (wave_specialised) thr = (rho >= 1.65) ? 64 : (ws_shared_simd ? 48 : 40);
       for (size_t l = w0; l < n_lanes && l < w0 + G; l++) dl[l].ready_min = thr;
     }
-    ready_min = tune.ready_min > 0 ? tune.ready_min : 0; /* 0: the groups' own thresholds */
+    ready_min = tune->ready_min > 0 ? tune->ready_min : 0; /* 0: the groups' own thresholds */
     /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
     lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
-    if (lds_bytes > VS_LDS_LIMIT) return VS_ERR_UNSUPPORTED;
-    /* wave-specialised launch shape: one pair = ring + cos rows + the two progress arrays; two
-     * pairs per workgroup when that gives one workgroup per CU AND both fit the CU's LDS; when
-     * not even one pair fits next to its progress words, the one-wave kernel runs instead */
+    if (lds_bytes > VS_LDS_LIMIT) {
+      rc = VS_ERR_UNSUPPORTED;
+      goto done;
+    }
+    /* wave-specialised launch shape: one group = ring + cos rows + its progress words; as many groups
+     * per workgroup as give one workgroup per CU AND fit the CU's LDS; when not even one group fits
+     * next to its progress words, the one-wave kernel runs instead */
     ws_pair_bytes = (int)((lds_bytes + 2 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
     if (wave_specialised) {
       if ((size_t)ws_pair_bytes > VS_LDS_LIMIT) wave_specialised = 0;
       ws_pairs = (grid <= cus) ? 1 : (grid <= 2u * cus ? 2 : 4);
-      if (tune.ws_pairs > 0) ws_pairs = tune.ws_pairs;
+      if (tune->ws_pairs > 0) ws_pairs = tune->ws_pairs;
       while (ws_pairs > 1 && (size_t)ws_pairs * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs >>= 1;
       /* Full grids (four groups per workgroup, the wavefronts of a group share a SIMD): three roles
        * -- open phase | noise | filter -- if the extra progress words and order boxes still fit next
@@ -658,29 +731,26 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * of two groups would put the open-phase wavefront on the FILTER's SIMD (6.4 ms). */
       if (wave_specialised && ws_pairs <= 2 && 2 * noisy >= n_lanes && all_deep && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)
         ws_roles = 3;
-      if (tune.ws_roles == 2) ws_roles = 2;
-      if (tune.ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+      if (tune->ws_roles == 2) ws_roles = 2;
+      if (tune->ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
       if (ws_roles == 3) ws_pair_bytes = bytes3;
       if (ws_roles == 3 && ws_pairs == 2) ws_layout = VS_WS_LAYOUT_SPREAD_2X3;
     }
   }
 
-  vs_plan *p = new (std::nothrow) vs_plan();
-  if (!p) return VS_ERR_NOMEM;
+  p = (vs_plan *)calloc(1, sizeof(vs_plan));
+  if (!p) {
+    rc = VS_ERR_NOMEM;
+    goto done;
+  }
   p->ctx = ctx;
   p->n_lanes = n_lanes;
   p->n_samples = n_samples;
-  p->d_lanes = nullptr;
-  p->d_costab = nullptr;
   p->ring_slots = slots;
   p->ready_min = ready_min;
   p->ltab_entries = ltab_entries;
   p->lds_bytes = lds_bytes;
   p->grid = grid;
-  p->d_diag = nullptr;
-  p->d_err = nullptr;
-  p->d_opow = nullptr;
-  p->d_sink = nullptr;
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
@@ -692,21 +762,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->filter_only = filter_only;
   p->pre1 = pre1 ? 1 : 0;
   p->wide = wide ? 1 : 0;
-  p->d_awide = nullptr;
-  p->d_flow = nullptr;
-  p->owns_flow = 0;
   p->flow_pitch = (n_samples + 7) & ~(size_t)7;
-  p->tuning = tune;
+  p->tuning = *tune;
 
-  const auto t_host1 = std::chrono::steady_clock::now();
+  const double t_host1 = vs_now_ms();
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
-  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab.size() + 1) * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab_len + 1) * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
-  if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, awide.size() * sizeof(double));
+  if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
   if (e == hipSuccess && wide && !filter_only) {
     const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
     if (mode & VS_PLAN_POOL_SCRATCH) {
@@ -724,13 +791,13 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
    * uses them is enqueued after this function has returned */
   hipStream_t up = ctx->upload ? ctx->upload : ctx->stream;
   if (e == hipSuccess && wide)
-    e = hipMemcpyAsync(p->d_awide, awide.data(), awide.size() * sizeof(double), hipMemcpyHostToDevice, up);
+    e = hipMemcpyAsync(p->d_awide, awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double), hipMemcpyHostToDevice, up);
   static const int zero_word = 0; /* a copy, not hipMemsetAsync: a process's first memset loads the runtime's fill kernel (20 ms) */
   if (e == hipSuccess) e = hipMemcpyAsync(p->d_err, &zero_word, sizeof(int), hipMemcpyHostToDevice, up);
   if (e == hipSuccess)
-    e = hipMemcpyAsync(p->d_lanes, dl.data(), n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
-  if (e == hipSuccess && !costab.empty())
-    e = hipMemcpyAsync(p->d_costab, costab.data(), costab.size() * sizeof(double), hipMemcpyHostToDevice, up);
+    e = hipMemcpyAsync(p->d_lanes, dl, n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
+  if (e == hipSuccess && costab_len)
+    e = hipMemcpyAsync(p->d_costab, costab, costab_len * sizeof(double), hipMemcpyHostToDevice, up);
   if (e == hipSuccess) e = hipStreamSynchronize(up);
   if (e != hipSuccess) {
     ctx->last_hip_error = (int)e;
@@ -741,23 +808,31 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (p->d_opow) (void)hipFree(p->d_opow);
     if (p->d_awide) (void)hipFree(p->d_awide);
     if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
-    delete p;
-    return VS_ERR_HIP;
+    free(p);
+    p = NULL;
+    rc = VS_ERR_HIP;
+    goto done;
   }
-  const auto t_host2 = std::chrono::steady_clock::now();
-  p->host_ms = std::chrono::duration<double, std::milli>(t_host1 - t_host0).count();
-  p->upload_ms = std::chrono::duration<double, std::milli>(t_host2 - t_host1).count();
+  const double t_host2 = vs_now_ms();
+  p->host_ms = t_host1 - t_host0;
+  p->upload_ms = t_host2 - t_host1;
   *out = p;
-  return VS_OK;
+  rc = VS_OK;
+done:
+  free(dl);
+  free(costab);
+  free(row_of_T2);
+  free(awide);
+  return rc;
 }
 
-extern "C" int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                               vs_plan **out)
 {
   return vs_plan_create_impl(ctx, lanes, n_lanes, n_samples, 0, out);
 }
 
-extern "C" void vs_plan_destroy(vs_plan *p)
+void vs_plan_destroy(vs_plan *p)
 {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
@@ -768,10 +843,10 @@ extern "C" void vs_plan_destroy(vs_plan *p)
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_awide) (void)hipFree(p->d_awide);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
-  delete p;
+  free(p);
 }
 
-extern "C" int vs_plan_status(vs_plan *p, int *flags)
+int vs_plan_status(vs_plan *p, int *flags)
 {
   if (!p) return VS_ERR_ARG;
   vs_ctx *ctx = p->ctx;
@@ -784,14 +859,14 @@ extern "C" int vs_plan_status(vs_plan *p, int *flags)
 }
 
 /* diagnostic builds (tools/diag_bench.py): device buffer of grid*8 uint64 cycle counters */
-extern "C" int vs_plan_set_diag(vs_plan *p, void *diag_dev)
+int vs_plan_set_diag(vs_plan *p, void *diag_dev)
 {
   if (!p) return VS_ERR_ARG;
   p->d_diag = (unsigned long long *)diag_dev;
   return VS_OK;
 }
 
-extern "C" int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_ms)
+int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_ms)
 {
   if (!p) return VS_ERR_ARG;
   if (host_ms) *host_ms = p->host_ms;
@@ -799,7 +874,7 @@ extern "C" int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_
   return VS_OK;
 }
 
-extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
+int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
 {
   if (!p || !buf || len == 0) return VS_ERR_ARG;
   if (p->wide && kind != VS_KIND_SOURCE) {
@@ -817,7 +892,7 @@ extern "C" int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t
   return VS_OK;
 }
 
-extern "C" int vs_plan_info(const vs_plan *p, size_t *lds_bytes, size_t *n_workgroups,
+int vs_plan_info(const vs_plan *p, size_t *lds_bytes, size_t *n_workgroups,
                             size_t *ring_slots)
 {
   if (!p) return VS_ERR_ARG;
@@ -827,7 +902,7 @@ extern "C" int vs_plan_info(const vs_plan *p, size_t *lds_bytes, size_t *n_workg
   return VS_OK;
 }
 
-extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
+int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
                               int16_t *out_dev, size_t out_pitch, vs_cycle_rec *log_dev,
                               size_t log_pitch, int32_t *ncyc_dev)
 {
@@ -844,7 +919,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.costab = p->d_costab;
   a.in = in_dev;
   a.out = out_dev;
-  a.log = (kind == VS_KIND_FILTER) ? nullptr : (void *)log_dev;
+  a.log = (kind == VS_KIND_FILTER) ? NULL : (void *)log_dev;
   a.ncyc = ncyc_dev;
   a.in_pitch = (long)in_pitch;
   a.out_pitch = (long)out_pitch;
@@ -860,7 +935,7 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
   a.diag = p->d_diag;
   a.err = p->d_err;
   a.sink = p->d_sink;
-  a.opow = (kind == VS_KIND_SOURCE) ? nullptr : p->d_opow;
+  a.opow = (kind == VS_KIND_SOURCE) ? NULL : p->d_opow;
   a.opow_pitch = p->opow_pitch;
   a.ws_pairs = p->ws_pairs;
   a.ws_roles = p->ws_roles;
@@ -897,19 +972,19 @@ extern "C" int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_
       VsKernelArgs src = a;
       src.out = p->d_flow;
       src.out_pitch = (long)p->flow_pitch;
-      src.opow = nullptr;
+      src.opow = NULL;
       src.vec_ok = 1; /* rows of the plan's own buffer start 16-byte aligned */
-      VS_HIP(ctx, vs_launch_kernel(ctx->arith, VS_KIND_SOURCE, src.log != nullptr, false, false, &src, p->grid,
+      VS_HIP(ctx, vs_launch_kernel(ctx->arith, VS_KIND_SOURCE, src.log != NULL, false, false, &src, p->grid,
                                    p->lds_bytes, ctx->stream));
       a.in = p->d_flow;
       a.in_pitch = (long)p->flow_pitch;
-      a.log = nullptr;
-      a.ncyc = nullptr;
+      a.log = NULL;
+      a.ncyc = NULL;
     }
     VS_HIP(ctx, vs_launch_filter_wide(ctx->arith, &a, p->grid, ctx->stream));
   } else {
-    VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != nullptr,
-                                 p->wave_specialised != 0 && a.opow == nullptr, p->pre1 != 0, &a, p->grid,
+    VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != NULL,
+                                 p->wave_specialised != 0 && a.opow == NULL, p->pre1 != 0, &a, p->grid,
                                  p->lds_bytes, ctx->stream));
   }
   if (a.opow) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream)); /* vowel -n, second half */

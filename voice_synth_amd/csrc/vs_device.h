@@ -34,7 +34,7 @@
 
 /* One utterance as the kernel reads it (296 bytes, 8-byte aligned).  Everything that is a
  * pure function of the lane's parameters is evaluated on the host, in C, with the reference's
- * operand types (vs_expand_lane() in vs_api.hip). */
+ * operand types (vs_expand_lane() in vs_api.c). */
 typedef struct VsDevLane {
   double a[22];       /* A[1..22]                                      vowel_new.c:279-281 */
   double gain;        /* (double)gain                                  vowel_new.c:268 */

@@ -423,7 +423,7 @@ int vs_wav_header_read(const unsigned char *buf, size_t avail, int32_t *fs, int 
 }
 
 /* ------------------------------------------------------------------------------------------
- * The bookkeeping of a node's gather (vs_node_synth_gather, csrc/vs_node.hip), without any device in
+ * The bookkeeping of a node's gather (vs_node_synth_gather, csrc/vs_node.c), without any device in
  * it: which lanes a shard owns, and which of its rows travel to the root in which round.  The sender
  * (a shard working through its chunks) and the receiver (the root posting one group of receives per
  * round) BOTH walk these functions, so the two sides of the exchange agree by construction;

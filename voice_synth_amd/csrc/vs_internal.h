@@ -1,11 +1,15 @@
 /*
  * vs_internal.h -- what the translation units of libvoicesynth share behind the C ABI:
  * the context and plan records, the context's buffer pool, internal entry points.
+ * Plain C: the host side of the library (vs_host.c, vs_api.c, vs_delivery.c, vs_node.c) is compiled by
+ * the C compiler against the HIP runtime's C API; only the kernels and their launchers (vs_kernels.hip)
+ * are HIP C++.
  */
 #ifndef VS_INTERNAL_H
 #define VS_INTERNAL_H
 
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime_api.h>
+#include <stdbool.h>
 
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
@@ -16,7 +20,7 @@
 
 /* Buffers a context keeps between calls (grown on demand, freed by vs_ctx_destroy or
  * vs_ctx_trim): nothing on the host-buffer paths calls hipMalloc / hipHostMalloc per call. */
-struct VsPool {
+typedef struct VsPool {
   void *d_out[2];           /* device PCM of the compute chunk in flight / being delivered */
   size_t d_out_bytes[2];
   void *d_in;               /* filter-only kind: the uploaded flow */
@@ -32,7 +36,7 @@ struct VsPool {
   hipStream_t upload_stream;  /* lane records + cos rows of the NEXT chunk's plan, while this chunk's kernel runs */
   hipEvent_t done[2];       /* kernel of the chunk in d_out[k] has finished */
   int streams_ready;
-};
+} VsPool;
 
 struct vs_ctx {
   int device;
@@ -88,6 +92,22 @@ struct vs_plan {
       return VS_ERR_HIP;                         \
     }                                            \
   } while (0)
+
+/* the launchers of csrc/vs_kernels.hip (extern "C" there) */
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
+hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
+hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream);
+hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1, const VsKernelArgs *args,
+                            unsigned grid, size_t lds_bytes, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+
+/* milliseconds on the monotonic clock */
+double vs_now_ms(void);
 
 /* mode: VS_PLAN_* bits */
 #define VS_PLAN_FILTER_ONLY 1  /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */

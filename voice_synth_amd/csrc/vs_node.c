@@ -1,5 +1,5 @@
 /*
- * vs_node.hip -- one batch over the GPUs of one node, in C (north star: "host code stays in C";
+ * vs_node.c -- one batch over the GPUs of one node, in C (north star: "host code stays in C";
  * SURVEY.md section 8b/8e).
  *
  * Utterances are independent -- all carried state of the reference is per utterance
@@ -43,31 +43,26 @@
  * node is back on the peer transport.  Which rows travel in which round is plain C without a device
  * in it (vs_gather_round, csrc/vs_host.c), walked by sender and receiver alike.
  *
- * One host thread per shard (a vs_ctx is used by one thread at a time).  The multi-PROCESS form
+ * One host thread per shard (pthreads; a vs_ctx is used by one thread at a time).  The multi-PROCESS form
  * of the same scheme -- one rank per GPU under torch.distributed.run, RCCL send/recv of the
  * chunks -- is what bench.py --gpus N runs; see voice_synth_amd/dist.py.
  */
+#define _GNU_SOURCE /* dladdr */
 #include <dlfcn.h>
-#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
 #include <string.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <mutex>
-#include <new>
-#include <thread>
-#include <vector>
 
 #include "vs_internal.h"
 
 #define VS_NODE_CHUNK 16384
+#define VS_NODE_MAX_SHARDS 64
 
 /* the handful of RCCL entry points the gather uses, resolved from librccl at run time (the types are
  * RCCL's: ncclComm_t is an opaque pointer, ncclResult_t and ncclDataType_t are ints, ncclInt8 == 0) */
 typedef void *vs_nccl_comm;
-struct VsRccl {
+typedef struct VsRccl {
   void *lib;
   int (*CommInitAll)(vs_nccl_comm *, int, const int *);
   int (*CommDestroy)(vs_nccl_comm);
@@ -76,51 +71,47 @@ struct VsRccl {
   int (*Recv)(void *, size_t, int, int, vs_nccl_comm, hipStream_t);
   int (*GroupStart)(void);
   int (*GroupEnd)(void);
-};
+} VsRccl;
 #define VS_NCCL_INT8 0
 
 struct vs_node {
-  std::vector<vs_ctx *> ctx;   /* one per shard */
-  std::vector<int> device;
-  std::vector<hipStream_t> compute, copy;
-  std::vector<hipEvent_t> ev_done[2], ev_copied[2];
-  std::vector<int> link;       /* VS_NODE_LINK_* of every shard */
-  std::vector<int> base_link;  /* ... as found at creation (self / peer / staged): what the peer transport uses */
-  int transport;               /* VS_NODE_TRANSPORT_* */
+  int n_shards;
+  vs_ctx *ctx[VS_NODE_MAX_SHARDS];   /* one per shard */
+  int device[VS_NODE_MAX_SHARDS];
+  hipStream_t compute[VS_NODE_MAX_SHARDS], copy[VS_NODE_MAX_SHARDS];
+  hipEvent_t ev_done[2][VS_NODE_MAX_SHARDS], ev_copied[2][VS_NODE_MAX_SHARDS];
+  int link[VS_NODE_MAX_SHARDS];       /* VS_NODE_LINK_* of every shard */
+  int base_link[VS_NODE_MAX_SHARDS];  /* ... as found at creation (self / peer / staged): what the peer transport uses */
+  int transport;                      /* VS_NODE_TRANSPORT_* */
   VsRccl rccl;
-  std::vector<vs_nccl_comm> comm;      /* one per shard (rank = shard), RCCL transport only */
-  std::vector<hipStream_t> recv;       /* on the root device: THE stream the root's receive groups are posted on */
+  int n_comm;                         /* communicators made (0 or n_shards), RCCL transport only */
+  vs_nccl_comm comm[VS_NODE_MAX_SHARDS]; /* one per shard (rank = shard) */
+  hipStream_t recv;                   /* on the root device: THE stream the root's receive groups are posted on */
   int last_rccl_error;
 };
 
-extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
+int vs_node_create(const int *devices, int n_shards, vs_node **out)
 {
-  if (!devices || n_shards <= 0 || n_shards > 64 || !out) return VS_ERR_ARG;
-  *out = nullptr;
-  vs_node *nd = new (std::nothrow) vs_node();
+  if (!devices || n_shards <= 0 || n_shards > VS_NODE_MAX_SHARDS || !out) return VS_ERR_ARG;
+  *out = NULL;
+  vs_node *nd = (vs_node *)calloc(1, sizeof(vs_node));
   if (!nd) return VS_ERR_NOMEM;
   nd->transport = VS_NODE_TRANSPORT_PEER;
-  memset(&nd->rccl, 0, sizeof(nd->rccl));
-  nd->last_rccl_error = 0;
   int rc = VS_OK;
   for (int s = 0; s < n_shards && rc == VS_OK; s++) {
-    vs_ctx *c = nullptr;
+    vs_ctx *c = NULL;
     rc = vs_ctx_create(devices[s], &c);
     if (rc != VS_OK) break;
-    nd->ctx.push_back(c);
-    nd->device.push_back(devices[s]);
-    hipStream_t a = nullptr, b = nullptr;
-    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    nd->ctx[s] = c;
+    nd->device[s] = devices[s];
+    nd->n_shards = s + 1;
     hipError_t he = hipSetDevice(devices[s]);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
-    for (int k = 0; k < 4 && he == hipSuccess; k++) he = hipEventCreateWithFlags(&e[k], hipEventDisableTiming);
-    nd->compute.push_back(a);
-    nd->copy.push_back(b);
-    nd->ev_done[0].push_back(e[0]);
-    nd->ev_done[1].push_back(e[1]);
-    nd->ev_copied[0].push_back(e[2]);
-    nd->ev_copied[1].push_back(e[3]);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&nd->compute[s], hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&nd->copy[s], hipStreamNonBlocking);
+    for (int k = 0; k < 2 && he == hipSuccess; k++) {
+      he = hipEventCreateWithFlags(&nd->ev_done[k][s], hipEventDisableTiming);
+      if (he == hipSuccess) he = hipEventCreateWithFlags(&nd->ev_copied[k][s], hipEventDisableTiming);
+    }
     if (he != hipSuccess) rc = VS_ERR_HIP;
     /* how this shard's PCM reaches the root: in place, by peer DMA, or -- when the device cannot
      * reach the root by peer access -- through host memory, which vs_node_link() says out loud */
@@ -135,8 +126,8 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
         (void)hipGetLastError();
       }
     }
-    nd->link.push_back(link);
-    nd->base_link.push_back(link);
+    nd->link[s] = link;
+    nd->base_link[s] = link;
   }
   if (rc != VS_OK) {
     vs_node_destroy(nd);
@@ -148,37 +139,39 @@ extern "C" int vs_node_create(const int *devices, int n_shards, vs_node **out)
 
 static void vs_node_drop_rccl(vs_node *nd)
 {
-  for (size_t s = 0; s < nd->comm.size(); s++) {
+  for (int s = 0; s < nd->n_comm; s++) {
     if (nd->comm[s] && nd->rccl.CommDestroy) {
       (void)hipSetDevice(nd->device[s]);
       (void)nd->rccl.CommDestroy(nd->comm[s]);
     }
+    nd->comm[s] = NULL;
   }
-  nd->comm.clear();
-  if (!nd->recv.empty()) (void)hipSetDevice(nd->device[0]);
-  for (hipStream_t st : nd->recv)
-    if (st) (void)hipStreamDestroy(st);
-  nd->recv.clear();
+  nd->n_comm = 0;
+  if (nd->recv) {
+    (void)hipSetDevice(nd->device[0]);
+    (void)hipStreamDestroy(nd->recv);
+    nd->recv = NULL;
+  }
   if (nd->rccl.lib) dlclose(nd->rccl.lib);
   memset(&nd->rccl, 0, sizeof(nd->rccl));
 }
 
-extern "C" int vs_node_set_transport(vs_node *nd, int transport)
+int vs_node_set_transport(vs_node *nd, int transport)
 {
   if (!nd || (transport != VS_NODE_TRANSPORT_PEER && transport != VS_NODE_TRANSPORT_RCCL)) return VS_ERR_ARG;
   if (transport == nd->transport) return VS_OK;
   if (transport == VS_NODE_TRANSPORT_PEER) {
     vs_node_drop_rccl(nd);
     nd->transport = transport;
-    nd->link = nd->base_link;
+    memcpy(nd->link, nd->base_link, sizeof(nd->link));
     return VS_OK;
   }
   /* RCCL puts one rank on one device: logical shards of one device cannot form a communicator */
-  const size_t S = nd->device.size();
-  for (size_t a = 0; a < S; a++)
-    for (size_t b = a + 1; b < S; b++)
+  const int S = nd->n_shards;
+  for (int a = 0; a < S; a++)
+    for (int b = a + 1; b < S; b++)
       if (nd->device[a] == nd->device[b]) return VS_ERR_UNSUPPORTED;
-  VsRccl &R = nd->rccl;
+  VsRccl *R = &nd->rccl;
   /* the RCCL that belongs to the HIP runtime this process runs on: the one next to libamdhip64
    * (a process may hold a second ROCm, e.g. the copy bundled with PyTorch, and RCCL on the wrong HSA
    * runtime finds no device), then whatever the loader finds by name */
@@ -191,144 +184,136 @@ extern "C" int vs_node_set_transport(vs_node *nd, int transport)
         const size_t dir = (size_t)(slash - info.dli_fname) + 1;
         memcpy(path, info.dli_fname, dir);
         strcpy(path + dir, "librccl.so.1");
-        R.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-        if (!R.lib) {
+        R->lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!R->lib) {
           strcpy(path + dir, "librccl.so");
-          R.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+          R->lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
         }
       }
     }
   }
-  if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-  if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-  if (!R.lib) return VS_ERR_UNSUPPORTED;
-  R.CommInitAll = (int (*)(vs_nccl_comm *, int, const int *))dlsym(R.lib, "ncclCommInitAll");
-  R.CommDestroy = (int (*)(vs_nccl_comm))dlsym(R.lib, "ncclCommDestroy");
-  R.CommAbort = (int (*)(vs_nccl_comm))dlsym(R.lib, "ncclCommAbort");
-  R.Send = (int (*)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclSend");
-  R.Recv = (int (*)(void *, size_t, int, int, vs_nccl_comm, hipStream_t))dlsym(R.lib, "ncclRecv");
-  R.GroupStart = (int (*)(void))dlsym(R.lib, "ncclGroupStart");
-  R.GroupEnd = (int (*)(void))dlsym(R.lib, "ncclGroupEnd");
-  if (!R.CommInitAll || !R.CommDestroy || !R.CommAbort || !R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
+  if (!R->lib) R->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!R->lib) R->lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!R->lib) return VS_ERR_UNSUPPORTED;
+  *(void **)&R->CommInitAll = dlsym(R->lib, "ncclCommInitAll");
+  *(void **)&R->CommDestroy = dlsym(R->lib, "ncclCommDestroy");
+  *(void **)&R->CommAbort = dlsym(R->lib, "ncclCommAbort");
+  *(void **)&R->Send = dlsym(R->lib, "ncclSend");
+  *(void **)&R->Recv = dlsym(R->lib, "ncclRecv");
+  *(void **)&R->GroupStart = dlsym(R->lib, "ncclGroupStart");
+  *(void **)&R->GroupEnd = dlsym(R->lib, "ncclGroupEnd");
+  if (!R->CommInitAll || !R->CommDestroy || !R->CommAbort || !R->Send || !R->Recv || !R->GroupStart || !R->GroupEnd) {
     vs_node_drop_rccl(nd);
     return VS_ERR_UNSUPPORTED;
   }
-  nd->comm.assign(S, nullptr);
-  const int e = R.CommInitAll(nd->comm.data(), (int)S, nd->device.data());
+  memset(nd->comm, 0, sizeof(nd->comm));
+  const int e = R->CommInitAll(nd->comm, S, nd->device);
   if (e != 0) {
     nd->last_rccl_error = e;
-    nd->comm.clear();
+    nd->n_comm = 0;
     vs_node_drop_rccl(nd);
     return VS_ERR_HIP;
   }
+  nd->n_comm = S;
   /* the root posts its receive groups on ONE stream of its own (concurrency inside a group of
    * point-to-point operations comes from RCCL's channels, not from streams) */
   hipError_t he = hipSetDevice(nd->device[0]);
-  if (he == hipSuccess) {
-    hipStream_t st = nullptr;
-    he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    nd->recv.push_back(st);
-  }
+  if (he == hipSuccess) he = hipStreamCreateWithFlags(&nd->recv, hipStreamNonBlocking);
   if (he != hipSuccess) {
     vs_node_drop_rccl(nd);
     return VS_ERR_HIP;
   }
   nd->transport = transport;
-  for (size_t s = 1; s < S; s++) nd->link[s] = VS_NODE_LINK_RCCL;
+  for (int s = 1; s < S; s++) nd->link[s] = VS_NODE_LINK_RCCL;
   return VS_OK;
 }
 
-extern "C" int vs_node_link(const vs_node *nd, int shard)
+int vs_node_link(const vs_node *nd, int shard)
 {
-  if (!nd || shard < 0 || shard >= (int)nd->link.size()) return VS_ERR_ARG;
-  return nd->link[(size_t)shard];
+  if (!nd || shard < 0 || shard >= nd->n_shards) return VS_ERR_ARG;
+  return nd->link[shard];
 }
 
-extern "C" int vs_node_last_rccl_error(const vs_node *nd) { return nd ? nd->last_rccl_error : 0; }
+int vs_node_last_rccl_error(const vs_node *nd) { return nd ? nd->last_rccl_error : 0; }
 
-extern "C" void vs_node_destroy(vs_node *nd)
+void vs_node_destroy(vs_node *nd)
 {
   if (!nd) return;
   vs_node_drop_rccl(nd);
-  for (size_t s = 0; s < nd->ctx.size(); s++) {
+  for (int s = 0; s < nd->n_shards; s++) {
     (void)hipSetDevice(nd->device[s]);
-    if (s < nd->compute.size() && nd->compute[s]) (void)hipStreamDestroy(nd->compute[s]);
-    if (s < nd->copy.size() && nd->copy[s]) (void)hipStreamDestroy(nd->copy[s]);
+    if (nd->compute[s]) (void)hipStreamDestroy(nd->compute[s]);
+    if (nd->copy[s]) (void)hipStreamDestroy(nd->copy[s]);
     for (int k = 0; k < 2; k++) {
-      if (s < nd->ev_done[k].size() && nd->ev_done[k][s]) (void)hipEventDestroy(nd->ev_done[k][s]);
-      if (s < nd->ev_copied[k].size() && nd->ev_copied[k][s]) (void)hipEventDestroy(nd->ev_copied[k][s]);
+      if (nd->ev_done[k][s]) (void)hipEventDestroy(nd->ev_done[k][s]);
+      if (nd->ev_copied[k][s]) (void)hipEventDestroy(nd->ev_copied[k][s]);
     }
     vs_ctx_destroy(nd->ctx[s]);
   }
-  delete nd;
+  free(nd);
 }
 
-extern "C" int vs_node_shards(const vs_node *nd) { return nd ? (int)nd->ctx.size() : 0; }
+int vs_node_shards(const vs_node *nd) { return nd ? nd->n_shards : 0; }
 
-extern "C" int vs_node_ctx(vs_node *nd, int shard, vs_ctx **ctx)
+int vs_node_ctx(vs_node *nd, int shard, vs_ctx **ctx)
 {
-  if (!nd || !ctx || shard < 0 || shard >= (int)nd->ctx.size()) return VS_ERR_ARG;
-  *ctx = nd->ctx[(size_t)shard];
+  if (!nd || !ctx || shard < 0 || shard >= nd->n_shards) return VS_ERR_ARG;
+  *ctx = nd->ctx[shard];
   return VS_OK;
 }
 
-extern "C" int vs_node_set_arith(vs_node *nd, int arith)
+int vs_node_set_arith(vs_node *nd, int arith)
 {
   if (!nd) return VS_ERR_ARG;
-  for (vs_ctx *c : nd->ctx) {
-    const int rc = vs_ctx_set_arith(c, arith);
+  for (int s = 0; s < nd->n_shards; s++) {
+    const int rc = vs_ctx_set_arith(nd->ctx[s], arith);
     if (rc != VS_OK) return rc;
   }
   return VS_OK;
 }
 
-/* lanes [lo, hi) of shard s: the cut of csrc/vs_host.c (vs_shard_cut), which the one-process-per-GPU
+/* lanes [lo, hi) of a shard: the cut of csrc/vs_host.c (vs_shard_cut), which the one-process-per-GPU
  * path makes too (voice_synth_amd/configs.py::shard_range) */
-static void shard_range(size_t n_lanes, size_t shards, size_t s, size_t *lo, size_t *hi)
+int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard, size_t *lo, size_t *hi)
 {
-  (void)vs_shard_cut(n_lanes, (int)shards, (int)s, lo, hi);
+  if (!nd || !lo || !hi || shard < 0 || shard >= nd->n_shards) return VS_ERR_ARG;
+  return vs_shard_cut(n_lanes, nd->n_shards, shard, lo, hi);
 }
 
-extern "C" int vs_node_shard_range(const vs_node *nd, size_t n_lanes, int shard, size_t *lo, size_t *hi)
-{
-  if (!nd || !lo || !hi || shard < 0 || shard >= (int)nd->ctx.size()) return VS_ERR_ARG;
-  shard_range(n_lanes, nd->ctx.size(), (size_t)shard, lo, hi);
-  return VS_OK;
-}
-
-namespace {
 /* where the shard threads of one gather meet: between "all of my chunk plans exist" and "the first
  * kernel / copy / send / receive is enqueued" */
-struct GatherSync {
-  std::mutex m;
-  std::condition_variable cv;
-  size_t parties = 0, waiting = 0;
-  unsigned generation = 0;
-  bool ok = true;                    /* cleared by a shard that failed to prepare */
-  std::atomic<bool> aborted{false};  /* set by a shard that failed once the exchange had started */
-  std::mutex abort_m;
+typedef struct GatherSync {
+  pthread_mutex_t m;
+  pthread_cond_t cv;
+  int parties, waiting;
+  unsigned generation;
+  bool ok;              /* cleared by a shard that failed to prepare */
+  atomic_bool aborted;  /* set by a shard that failed once the exchange had started */
+  pthread_mutex_t abort_m;
+} GatherSync;
 
-  /* every shard calls this once; returns the verdict of all of them */
-  bool arrive(bool mine)
-  {
-    std::unique_lock<std::mutex> lk(m);
-    if (!mine) ok = false;
-    const unsigned gen = generation;
-    if (++waiting == parties) {
-      waiting = 0;
-      generation++;
-      cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != gen; });
-    }
-    return ok;
+/* every shard calls this once; returns the verdict of all of them */
+static bool gather_arrive(GatherSync *g, bool mine)
+{
+  pthread_mutex_lock(&g->m);
+  if (!mine) g->ok = false;
+  const unsigned gen = g->generation;
+  if (++g->waiting == g->parties) {
+    g->waiting = 0;
+    g->generation++;
+    pthread_cond_broadcast(&g->cv);
+  } else {
+    while (g->generation == gen) pthread_cond_wait(&g->cv, &g->m);
   }
-};
+  const bool verdict = g->ok;
+  pthread_mutex_unlock(&g->m);
+  return verdict;
+}
 
-struct ShardJob {
+typedef struct ShardJob {
   vs_node *nd;
   GatherSync *sync;
-  size_t s;
+  int s;
   const vs_lane *lanes;
   size_t lo, hi, n_samples, n_total;
   int16_t *root;      /* device pointer on device[0]: int16 [n_lanes][root_pitch] */
@@ -336,31 +321,37 @@ struct ShardJob {
   int flags;          /* VS_NODE_OVERLAP, VS_NODE_STAGE_ALL */
   int rc;
   double compute_ms;  /* host clock: first launch .. last kernel done */
-};
+} ShardJob;
 
 /* A shard failed after the exchange had started: peers may hold sends nobody will receive, the root
  * receives nobody will send.  ncclCommAbort ends the kernels of the operations in flight, so that the
  * streams they sit on can be waited for again; the communicators are gone afterwards (the caller of
  * vs_node_synth_gather drops the transport).  Once per gather, whoever comes first. */
-void abort_exchange(vs_node *nd, GatherSync *sync)
+static void abort_exchange(vs_node *nd, GatherSync *sync)
 {
-  std::lock_guard<std::mutex> lk(sync->abort_m);
-  if (sync->aborted.exchange(true)) return;
-  if (nd->transport != VS_NODE_TRANSPORT_RCCL) return;
-  for (size_t p = 0; p < nd->comm.size(); p++) {
-    if (nd->comm[p]) {
-      (void)nd->rccl.CommAbort(nd->comm[p]);
-      nd->comm[p] = nullptr;
+  pthread_mutex_lock(&sync->abort_m);
+  if (!atomic_exchange(&sync->aborted, true) && nd->transport == VS_NODE_TRANSPORT_RCCL) {
+    for (int p = 0; p < nd->n_comm; p++) {
+      if (nd->comm[p]) {
+        (void)nd->rccl.CommAbort(nd->comm[p]);
+        nd->comm[p] = NULL;
+      }
     }
   }
+  pthread_mutex_unlock(&sync->abort_m);
 }
 
-void shard_gather(ShardJob *j)
+typedef struct Chunk {
+  size_t row0, rows;
+} Chunk;
+
+static void *shard_gather(void *arg)
 {
+  ShardJob *j = (ShardJob *)arg;
   vs_node *nd = j->nd;
   GatherSync *sync = j->sync;
-  const size_t s = j->s;
-  const size_t S = nd->ctx.size();
+  const int s = j->s;
+  const int S = nd->n_shards;
   vs_ctx *ctx = nd->ctx[s];
   j->rc = VS_OK;
   j->compute_ms = 0.0;
@@ -371,53 +362,54 @@ void shard_gather(ShardJob *j)
    * receives are posted behind that launch: the peers' first chunks are not finished before the
    * root's own kernel is either) */
   const bool in_place = (nd->device[s] == nd->device[0]) && !((j->flags & VS_NODE_STAGE_ALL) && !rccl);
-  const size_t chunk = in_place ? std::max<size_t>(rows_all, 1) : VS_NODE_CHUNK;
+  const size_t chunk = in_place ? (rows_all ? rows_all : 1) : VS_NODE_CHUNK;
   /* an RCCL message is one contiguous range: chunks are synthesised at pitch n_samples and land in a
    * root buffer of that pitch (checked by the caller) */
   const size_t pitch = rccl ? j->n_samples : ((j->n_samples + 7) & ~(size_t)7);
-  VsPool &P = ctx->pool;
+  VsPool *P = &ctx->pool;
   hipStream_t saved = ctx->stream;
-  std::vector<vs_plan *> plans;
-  struct Chunk { size_t row0, rows; };
-  std::vector<Chunk> chunks;
+  const size_t n_chunks = rows_all ? (rows_all + chunk - 1) / chunk : 0;
+  Chunk *chunks = (Chunk *)calloc(n_chunks ? n_chunks : 1, sizeof(Chunk));
+  vs_plan **plans = (vs_plan **)calloc(n_chunks ? n_chunks : 1, sizeof(vs_plan *));
+  size_t n_plans = 0;
 
   /* ---- prepare: buffers and the plans of ALL chunks; nothing is enqueued yet ---- */
-  if (hipSetDevice(nd->device[s]) != hipSuccess) j->rc = VS_ERR_HIP;
+  if (!chunks || !plans) j->rc = VS_ERR_NOMEM;
+  if (j->rc == VS_OK && hipSetDevice(nd->device[s]) != hipSuccess) j->rc = VS_ERR_HIP;
   if (j->rc == VS_OK && rows_all > 0) {
-    for (size_t round = 0;; round++) {
-      size_t row0 = 0, rows = 0;
+    for (size_t c = 0; c < n_chunks; c++) {
       if (in_place) {
-        if (round > 0) break;
-        row0 = j->lo;
-        rows = rows_all;
-      } else if (vs_gather_round(j->n_total, (int)S, (int)s, VS_NODE_CHUNK, round, &row0, &rows) != VS_OK || rows == 0) {
+        chunks[c].row0 = j->lo;
+        chunks[c].rows = rows_all;
+      } else if (vs_gather_round(j->n_total, S, s, VS_NODE_CHUNK, c, &chunks[c].row0, &chunks[c].rows) != VS_OK || chunks[c].rows == 0) {
+        j->rc = VS_ERR_INTERNAL; /* cannot happen: n_chunks comes from the same cut */
         break;
       }
-      chunks.push_back({row0, rows});
     }
     if (!in_place) {
-      for (int k = 0; k < 2 && j->rc == VS_OK && (k == 0 || chunks.size() > 1); k++)
-        j->rc = vs_pool_device(ctx, &P.d_out[k], &P.d_out_bytes[k], std::min(rows_all, chunk) * pitch * sizeof(int16_t));
+      const size_t first = rows_all < chunk ? rows_all : chunk;
+      for (int k = 0; k < 2 && j->rc == VS_OK && (k == 0 || n_chunks > 1); k++)
+        j->rc = vs_pool_device(ctx, &P->d_out[k], &P->d_out_bytes[k], first * pitch * sizeof(int16_t));
     }
     ctx->stream = nd->compute[s];
-    for (size_t c = 0; c < chunks.size() && j->rc == VS_OK; c++) {
-      vs_plan *plan = nullptr;
+    for (size_t c = 0; c < n_chunks && j->rc == VS_OK; c++) {
+      vs_plan *plan = NULL;
       j->rc = vs_plan_create_impl(ctx, j->lanes + chunks[c].row0, chunks[c].rows, j->n_samples, VS_PLAN_POOL_SCRATCH, &plan);
-      if (j->rc == VS_OK) plans.push_back(plan);
+      if (j->rc == VS_OK) plans[n_plans++] = plan;
     }
     if (j->rc == VS_OK && ctx->tuning.fault == VS_FAULT_SHARD_PREPARE) j->rc = VS_ERR_INTERNAL; /* tests */
   }
   /* ---- all or nothing: one shard that cannot go on keeps every shard from starting ---- */
-  const bool go = sync->arrive(j->rc == VS_OK);
+  const bool go = gather_arrive(sync, j->rc == VS_OK);
 
-  const auto t0 = std::chrono::steady_clock::now();
+  const double t0 = vs_now_ms();
   bool used[2] = {false, false};
   int k = 0;
-  for (size_t c = 0; go && c < chunks.size() && j->rc == VS_OK && !sync->aborted.load(); c++, k ^= 1) {
+  for (size_t c = 0; go && c < n_plans && j->rc == VS_OK && !atomic_load(&sync->aborted); c++, k ^= 1) {
     const size_t r0 = chunks[c].row0, rows = chunks[c].rows;
     int16_t *dst = j->root + r0 * j->root_pitch;
     if (in_place) {
-      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, nullptr, 0, dst, j->root_pitch, nullptr, 0, nullptr);
+      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, NULL, 0, dst, j->root_pitch, NULL, 0, NULL);
       if (j->rc == VS_OK && ctx->tuning.fault == VS_FAULT_SHARD_HANDOVER) j->rc = VS_ERR_INTERNAL; /* tests */
       continue;
     }
@@ -425,7 +417,7 @@ void shard_gather(ShardJob *j)
     hipError_t e = hipSuccess;
     if (used[k]) e = hipStreamWaitEvent(nd->compute[s], nd->ev_copied[k][s], 0);
     if (e == hipSuccess) {
-      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, nullptr, 0, (int16_t *)P.d_out[k], pitch, nullptr, 0, nullptr);
+      j->rc = vs_plan_launch(plans[c], VS_KIND_SYNTH, NULL, 0, (int16_t *)P->d_out[k], pitch, NULL, 0, NULL);
       if (j->rc == VS_OK && c == 0 && ctx->tuning.fault == VS_FAULT_SHARD_HANDOVER) j->rc = VS_ERR_INTERNAL; /* tests */
       if (j->rc != VS_OK) break;
       e = hipEventRecord(nd->ev_done[k][s], nd->compute[s]);
@@ -434,7 +426,7 @@ void shard_gather(ShardJob *j)
       /* the chunk leaves by ncclSend behind its kernel; the root's thread posts the matching receive */
       e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
       if (e == hipSuccess) {
-        const int ne = nd->rccl.Send(P.d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
+        const int ne = nd->rccl.Send(P->d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
         if (ne != 0) {
           nd->last_rccl_error = ne;
           j->rc = VS_ERR_HIP;
@@ -446,7 +438,7 @@ void shard_gather(ShardJob *j)
     } else if (e == hipSuccess && (j->flags & VS_NODE_OVERLAP)) {
       e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
       if (e == hipSuccess)
-        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P.d_out[k], pitch * 2, j->n_samples * 2, rows,
+        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P->d_out[k], pitch * 2, j->n_samples * 2, rows,
                              hipMemcpyDefault, nd->copy[s]);
       if (e == hipSuccess) e = hipEventRecord(nd->ev_copied[k][s], nd->copy[s]);
       used[k] = true;
@@ -455,7 +447,7 @@ void shard_gather(ShardJob *j)
        * the two buffers force a wait here, which is the point of the comparison */
       e = hipStreamSynchronize(nd->compute[s]);
       if (e == hipSuccess)
-        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P.d_out[k], pitch * 2, j->n_samples * 2, rows,
+        e = hipMemcpy2DAsync(dst, j->root_pitch * 2, P->d_out[k], pitch * 2, j->n_samples * 2, rows,
                              hipMemcpyDefault, nd->copy[s]);
       if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
     }
@@ -467,14 +459,14 @@ void shard_gather(ShardJob *j)
   if (go && rccl && s == 0 && j->rc == VS_OK && S > 1) {
     /* the root's side of the exchange: round k = chunk k of every peer that has one, as one group on
      * one stream, straight into the peer's rows of the root buffer */
-    const size_t rounds = vs_gather_rounds(j->n_total, (int)S, VS_NODE_CHUNK);
-    for (size_t kk = 0; kk < rounds && j->rc == VS_OK && !sync->aborted.load(); kk++) {
+    const size_t rounds = vs_gather_rounds(j->n_total, S, VS_NODE_CHUNK);
+    for (size_t kk = 0; kk < rounds && j->rc == VS_OK && !atomic_load(&sync->aborted); kk++) {
       int ne = nd->rccl.GroupStart();
-      for (size_t p = 1; p < S && ne == 0; p++) {
+      for (int p = 1; p < S && ne == 0; p++) {
         size_t r0 = 0, rows = 0;
-        if (vs_gather_round(j->n_total, (int)S, (int)p, VS_NODE_CHUNK, kk, &r0, &rows) != VS_OK || rows == 0) continue;
-        ne = nd->rccl.Recv(j->root + r0 * j->root_pitch, rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, (int)p,
-                           nd->comm[0], nd->recv[0]);
+        if (vs_gather_round(j->n_total, S, p, VS_NODE_CHUNK, kk, &r0, &rows) != VS_OK || rows == 0) continue;
+        ne = nd->rccl.Recv(j->root + r0 * j->root_pitch, rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, p,
+                           nd->comm[0], nd->recv);
       }
       const int ge = nd->rccl.GroupEnd();
       if (ne == 0) ne = ge;
@@ -488,115 +480,140 @@ void shard_gather(ShardJob *j)
   if (go && j->rc != VS_OK) abort_exchange(nd, sync);
   if (go && hipSetDevice(nd->device[s]) == hipSuccess) {
     hipError_t e = hipStreamSynchronize(nd->compute[s]);
-    j->compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    j->compute_ms = vs_now_ms() - t0;
     if (e == hipSuccess) e = hipStreamSynchronize(nd->copy[s]);
-    if (e == hipSuccess && rccl && s == 0 && !nd->recv.empty()) e = hipStreamSynchronize(nd->recv[0]);
+    if (e == hipSuccess && rccl && s == 0 && nd->recv) e = hipStreamSynchronize(nd->recv);
     if (e != hipSuccess && j->rc == VS_OK) {
       ctx->last_hip_error = (int)e;
       j->rc = VS_ERR_HIP;
     }
-    for (vs_plan *pl : plans) {
-      const int st = vs_plan_status(pl, nullptr);
-      if (j->rc == VS_OK && st != VS_OK && !sync->aborted.load()) j->rc = st;
+    for (size_t c = 0; c < n_plans; c++) {
+      const int st = vs_plan_status(plans[c], NULL);
+      if (j->rc == VS_OK && st != VS_OK && !atomic_load(&sync->aborted)) j->rc = st;
     }
   }
-  for (vs_plan *pl : plans) vs_plan_destroy(pl);
+  for (size_t c = 0; c < n_plans; c++) vs_plan_destroy(plans[c]);
   ctx->stream = saved;
+  free(chunks);
+  free(plans);
+  return NULL;
 }
-}  // namespace
 
-extern "C" int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                                    int16_t *root_dev, size_t root_pitch, int flags, double *total_ms,
-                                    double *max_compute_ms)
+int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                         int16_t *root_dev, size_t root_pitch, int flags, double *total_ms,
+                         double *max_compute_ms)
 {
   if (!nd || !lanes || !root_dev || n_lanes == 0 || n_samples == 0 || root_pitch < n_samples) return VS_ERR_ARG;
   /* RCCL messages are contiguous: the root buffer must be packed */
   if (nd->transport == VS_NODE_TRANSPORT_RCCL && root_pitch != n_samples) return VS_ERR_UNSUPPORTED;
-  const size_t S = nd->ctx.size();
-  std::vector<ShardJob> jobs(S);
-  std::vector<std::thread> th;
+  const int S = nd->n_shards;
+  ShardJob jobs[VS_NODE_MAX_SHARDS];
+  pthread_t th[VS_NODE_MAX_SHARDS];
   GatherSync sync;
+  memset(&sync, 0, sizeof(sync));
+  pthread_mutex_init(&sync.m, NULL);
+  pthread_mutex_init(&sync.abort_m, NULL);
+  pthread_cond_init(&sync.cv, NULL);
   sync.parties = S;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (size_t s = 0; s < S; s++) {
-    ShardJob &j = jobs[s];
-    j.nd = nd;
-    j.sync = &sync;
-    j.s = s;
-    j.lanes = lanes;
-    shard_range(n_lanes, S, s, &j.lo, &j.hi);
-    j.n_samples = n_samples;
-    j.n_total = n_lanes;
-    j.root = root_dev;
-    j.root_pitch = root_pitch;
-    j.flags = flags;
-    j.rc = VS_OK;
+  sync.ok = true;
+  atomic_init(&sync.aborted, false);
+  const double t0 = vs_now_ms();
+  for (int s = 0; s < S; s++) {
+    ShardJob *j = &jobs[s];
+    j->nd = nd;
+    j->sync = &sync;
+    j->s = s;
+    j->lanes = lanes;
+    (void)vs_shard_cut(n_lanes, S, s, &j->lo, &j->hi);
+    j->n_samples = n_samples;
+    j->n_total = n_lanes;
+    j->root = root_dev;
+    j->root_pitch = root_pitch;
+    j->flags = flags;
+    j->rc = VS_OK;
+    j->compute_ms = 0.0;
   }
-  try {
-    for (size_t s = 0; s < S; s++) th.emplace_back(shard_gather, &jobs[s]);
-  } catch (...) {
-    /* the shards that did start are waiting for the ones that never will: stand in for those, with a no */
-    for (size_t s = th.size(); s < S; s++) (void)sync.arrive(false);
-    for (auto &x : th) x.join();
-    return VS_ERR_NOMEM;
+  int started = 0;
+  for (int s = 0; s < S; s++) {
+    if (pthread_create(&th[s], NULL, shard_gather, &jobs[s]) != 0) break;
+    started++;
   }
-  for (auto &x : th) x.join();
-  if (total_ms) *total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  /* the shards that did start are waiting for the ones that never will: stand in for those, with a no */
+  for (int s = started; s < S; s++) (void)gather_arrive(&sync, false);
+  for (int s = 0; s < started; s++) pthread_join(th[s], NULL);
+  if (total_ms) *total_ms = vs_now_ms() - t0;
   double mc = 0.0;
-  int rc = VS_OK;
-  for (size_t s = 0; s < S; s++) {
-    mc = std::max(mc, jobs[s].compute_ms);
+  int rc = (started < S) ? VS_ERR_NOMEM : VS_OK;
+  for (int s = 0; s < started; s++) {
+    if (jobs[s].compute_ms > mc) mc = jobs[s].compute_ms;
     if (rc == VS_OK && jobs[s].rc != VS_OK) rc = jobs[s].rc;
   }
   if (max_compute_ms) *max_compute_ms = mc;
-  if (sync.aborted.load() && nd->transport == VS_NODE_TRANSPORT_RCCL) {
+  if (atomic_load(&sync.aborted) && nd->transport == VS_NODE_TRANSPORT_RCCL) {
     /* the communicators were aborted: the node is back on the peer transport (vs_node_set_transport makes new ones) */
     vs_node_drop_rccl(nd);
     nd->transport = VS_NODE_TRANSPORT_PEER;
-    nd->link = nd->base_link;
+    memcpy(nd->link, nd->base_link, sizeof(nd->link));
   }
+  pthread_cond_destroy(&sync.cv);
+  pthread_mutex_destroy(&sync.abort_m);
+  pthread_mutex_destroy(&sync.m);
   return rc;
 }
 
-namespace {
-struct RowsShift {
+typedef struct RowsJob {
+  vs_node *nd;
+  int s;
+  const vs_lane *lanes;
+  size_t lo, hi, n_samples;
   vs_rows_cb cb;
   void *user;
-  size_t lo;
-};
-int shifted(void *u, size_t row0, size_t rows, const int16_t *pcm)
+  int rc;
+} RowsJob;
+
+static int shifted(void *u, size_t row0, size_t rows, const int16_t *pcm)
 {
-  RowsShift *r = (RowsShift *)u;
+  RowsJob *r = (RowsJob *)u;
   return r->cb(r->user, r->lo + row0, rows, pcm);
 }
-}  // namespace
 
-extern "C" int vs_node_synth_rows(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
-                                  vs_rows_cb cb, void *user)
+static void *shard_rows(void *arg)
+{
+  RowsJob *r = (RowsJob *)arg;
+  r->rc = vs_synth_rows(r->nd->ctx[r->s], r->lanes + r->lo, r->hi - r->lo, r->n_samples, shifted, r);
+  return NULL;
+}
+
+int vs_node_synth_rows(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
+                       vs_rows_cb cb, void *user)
 {
   if (!nd || !lanes || !cb || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
-  const size_t S = nd->ctx.size();
-  std::vector<int> rcs(S, VS_OK);
-  std::vector<RowsShift> sh(S);
-  std::vector<std::thread> th;
-  try {
-    for (size_t s = 0; s < S; s++) {
-      size_t lo, hi;
-      shard_range(n_lanes, S, s, &lo, &hi);
-      if (lo >= hi) continue;
-      sh[s].cb = cb;
-      sh[s].user = user;
-      sh[s].lo = lo;
-      th.emplace_back([=, &rcs, &sh]() {
-        rcs[s] = vs_synth_rows(nd->ctx[s], lanes + lo, hi - lo, n_samples, shifted, &sh[s]);
-      });
+  const int S = nd->n_shards;
+  RowsJob jobs[VS_NODE_MAX_SHARDS];
+  pthread_t th[VS_NODE_MAX_SHARDS];
+  bool running[VS_NODE_MAX_SHARDS];
+  int rc = VS_OK;
+  for (int s = 0; s < S; s++) {
+    RowsJob *r = &jobs[s];
+    running[s] = false;
+    r->nd = nd;
+    r->s = s;
+    r->lanes = lanes;
+    (void)vs_shard_cut(n_lanes, S, s, &r->lo, &r->hi);
+    r->n_samples = n_samples;
+    r->cb = cb;
+    r->user = user;
+    r->rc = VS_OK;
+    if (r->lo >= r->hi) continue;
+    if (pthread_create(&th[s], NULL, shard_rows, r) != 0) {
+      rc = VS_ERR_NOMEM;
+      break;
     }
-  } catch (...) {
-    for (auto &x : th) x.join();
-    return VS_ERR_NOMEM;
+    running[s] = true;
   }
-  for (auto &x : th) x.join();
-  for (size_t s = 0; s < S; s++)
-    if (rcs[s] != VS_OK) return rcs[s];
-  return VS_OK;
+  for (int s = 0; s < S; s++)
+    if (running[s]) pthread_join(th[s], NULL);
+  for (int s = 0; s < S && rc == VS_OK; s++)
+    if (running[s] && jobs[s].rc != VS_OK) rc = jobs[s].rc;
+  return rc;
 }
