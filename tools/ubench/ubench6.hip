@@ -50,10 +50,6 @@ struct R6 {
   unsigned la;
 };
 
-#define MF16(C, A, B) "v_mfma_f64_16x16x4_f64 %" #C ", %" #A ", %" #B ", %" #C "\n\t"
-#define FMA(D) "v_fma_f64 %" #D ", %" #D ", %[g0], %[g1]\n\t"
-#define XOR(D) "v_xor_b32 %" #D ", %" #D ", %[w0]\n\t"
-
 template <int O>
 __device__ __forceinline__ void body6(R6 &r)
 {
