@@ -21,7 +21,7 @@ KERNEL_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_dev_primitives.h $(CSRC)/vs_dev_ge
 HIPFLAGS := -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
 CFLAGS   := -O2 -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -Wno-unused-parameter
 HOSTFLAGS := -std=gnu11 $(CFLAGS) -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include
-HOST_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_internal.h include/voice_synth.h
+HOST_HDRS := $(CSRC)/vs_device.h $(CSRC)/vs_internal.h $(CSRC)/vs_planhost.h include/voice_synth.h
 
 LIB := $(LIBDIR)/libvoicesynth.so
 
@@ -44,13 +44,16 @@ $(CSRC)/vs_kernels_narrow.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 $(CSRC)/vs_api.o: $(CSRC)/vs_api.c $(HOST_HDRS)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
+$(CSRC)/vs_planhost.o: $(CSRC)/vs_planhost.c $(CSRC)/vs_planhost.h $(CSRC)/vs_device.h include/voice_synth.h
+	$(CC) -std=gnu11 $(CFLAGS) -c -o $@ $<
+
 $(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.c $(HOST_HDRS)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
 $(CSRC)/vs_node.o: $(CSRC)/vs_node.c $(HOST_HDRS)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
+$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
@@ -75,14 +78,14 @@ clean:
 diag: $(LIBDIR)/libvoicesynth_diag.so
 $(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
-$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
+$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 # A/B variants of the library for same-box comparisons (tools/gpu_ab.sh):
 #   make variant NAME=sleep2 DEFS="-DVS_POLL_SLEEP=2"   ->  lib/libvoicesynth_sleep2.so   (select with VS_LIB)
-variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o | $(LIBDIR)
+variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels.hip
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o -lm -lpthread -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o -lm -lpthread -ldl
 
 # device listing of the shipped kernels (same flags) for tools/isa_loops.py
 isa:

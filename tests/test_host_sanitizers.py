@@ -1,5 +1,5 @@
-"""Host-side C of the product (voice_synth_amd/csrc/vs_host.c) and the CPU oracle under
-AddressSanitizer + UndefinedBehaviorSanitizer.  CPU builds only: GPU sanitizers are not
+"""Host-side C of the product (voice_synth_amd/csrc/vs_host.c, vs_planhost.c: everything of the host side that needs
+no device) and the CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer.  CPU builds only: GPU sanitizers are not
 available on this pool."""
 import os
 import subprocess
@@ -13,6 +13,19 @@ def test_host_c_under_asan_ubsan(tmp_path):
     subprocess.run(["gcc"] + SAN + [os.path.join(ROOT, "tests", "c", "test_host_asan.c"),
                                     os.path.join(ROOT, "voice_synth_amd", "csrc", "vs_host.c"),
                                     "-I" + os.path.join(ROOT, "include"), "-o", exe, "-lm"], check=True)
+    r = subprocess.run([exe], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert r.stdout.strip() == b"ok"
+
+
+def test_plan_host_c_under_asan_ubsan(tmp_path):
+    """the device-free half of plan creation: expansion on 8 threads, the stable order, the ring policy, the gather
+    rounds (tests/c/test_planhost_asan.c)"""
+    exe = str(tmp_path / "test_planhost_asan")
+    csrc = os.path.join(ROOT, "voice_synth_amd", "csrc")
+    subprocess.run(["gcc", "-std=gnu11"] + SAN + [os.path.join(ROOT, "tests", "c", "test_planhost_asan.c"),
+                                                  os.path.join(csrc, "vs_planhost.c"), os.path.join(csrc, "vs_host.c"),
+                                                  "-I" + os.path.join(ROOT, "include"), "-o", exe, "-lm", "-lpthread"], check=True)
     r = subprocess.run([exe], capture_output=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert r.stdout.strip() == b"ok"

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #define VS_WAVE 64 /* lanes per wavefront on gfx950: one utterance per lane */
+#define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
 #define VS_NARROW_LANES 16 /* utterances per wavefront of the narrow build (periods beyond the 64-column ring) */
 #define VS_SS 24   /* samples per filter super-step == size of the rotating y[] register window */
 

@@ -1,7 +1,7 @@
 /*
  * vs_internal.h -- what the translation units of libvoicesynth share behind the C ABI:
  * the context and plan records, the context's buffer pool, internal entry points.
- * Plain C: the host side of the library (vs_host.c, vs_api.c, vs_delivery.c, vs_node.c) is compiled by
+ * Plain C: the host side of the library (vs_host.c, vs_planhost.c, vs_api.c, vs_delivery.c, vs_node.c) is compiled by
  * the C compiler against the HIP runtime's C API; only the kernels and their launchers (vs_kernels.hip)
  * are HIP C++.
  */
@@ -13,8 +13,8 @@
 
 #include "../../include/voice_synth.h"
 #include "vs_device.h"
+#include "vs_planhost.h"
 
-#define VS_LDS_LIMIT (160 * 1024) /* LDS per CU on gfx950 */
 #define VS_DELIVERY_THREADS 4     /* row-chunk delivery workers (each: one stream + one pinned staging buffer) */
 #define VS_STAGING_BYTES (16u << 20)
 

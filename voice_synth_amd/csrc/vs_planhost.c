@@ -1,0 +1,300 @@
+/*
+ * vs_planhost.c -- the part of plan creation that needs no device: a lane's parameters expanded into the record the
+ * kernels read (everything that is a pure function of the parameters, evaluated with the reference's operand
+ * types), the cos rows, the ring policy, the order of the lanes.  Plain C without a HIP header in sight, so that it
+ * runs under AddressSanitizer / UBSan on the CPU (tests/test_host_sanitizers.py); vs_api.c does the rest.
+ *
+ *   P  = (int)((float)fs/F0)                     flowgen_shimmer.c:244
+ *   T2 = ceil(0.5*cq*P)                          flowgen_shimmer.c:317
+ *   cos(PI*k/T2), k = 0..T2-1                    flowgen_shimmer.c:319, 328 (same arguments in
+ *                                                both half-pulses; PI is 4.0*atan(1.0), fg:39)
+ *   (float)1.2*P, (float)0.8*P                   flowgen_shimmer.c:290
+ *   (float)1.8*amp, (float)0.2*amp               flowgen_shimmer.c:306
+ * This translation unit is compiled with -ffp-contract=off.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "vs_planhost.h"
+
+/* ------------------------------------------------------------------------------------------
+ * Host expansion of one lane (no device needed; exported for the CPU-side tests)
+ * ---------------------------------------------------------------------------------------- */
+/* A[0..40] of the lane's filter: the table or the explicit set, zeros behind its order */
+int vs_lane_taps(const vs_lane *lane, double *A)
+{
+  for (int j = 0; j < VS_MAX_NCOEF; j++) A[j] = 0.0;
+  if (lane->vowel != VS_VOWEL_CUSTOM) return vs_vowel_coefficients(lane->vowel, A);
+  int order = 0;
+  const int rc = vs_lane_order(lane, &order);
+  if (rc != VS_OK) return rc;
+  for (int j = 0; j <= order; j++) A[j] = lane->A[j];
+  return VS_OK;
+}
+
+bool vs_lane_is_wide(const vs_lane *lane)
+{
+  return lane->vowel == VS_VOWEL_CUSTOM && lane->order > VS_ORDER;
+}
+
+int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
+{
+  int rc = vs_lane_validate(lane);
+  if (rc != VS_OK) return rc;
+  double A[VS_MAX_NCOEF];
+  if ((rc = vs_lane_taps(lane, A)) != VS_OK) return rc;
+  memset(d, 0, sizeof(*d));
+  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j]; /* a wide set's first 22 taps: unused, the plan is wide */
+  d->gain = (double)lane->gain;
+  d->pre = (double)lane->pre_emphasis;
+  d->jitter = lane->jitter;
+  d->shimmer = lane->shimmer;
+  d->K = lane->K;
+  d->Kvar = lane->Kvar;
+  d->DC = lane->DC;
+  d->noise = lane->noise;
+  d->amp = lane->amp;
+  const int P = (int)((float)lane->fs / lane->F0);
+  d->P = P;
+  d->T2 = (int)ceil(0.5 * lane->cq * P);
+  d->t_hi = (float)1.2 * P;
+  d->t_lo = (float)0.8 * P;
+  d->a_hi = (float)1.8 * lane->amp;
+  d->a_lo = (float)0.2 * lane->amp;
+  d->dcs = (int32_t)(int16_t)(int32_t)lane->DC;
+  uint32_t f = 0;
+  if ((lane->flags & VS_FLAG_JITTER) && lane->jitter != 0.0) f |= VS_DF_JITTER;
+  if ((lane->flags & VS_FLAG_SHIMMER) && lane->shimmer != 0.0) f |= VS_DF_SHIMMER;
+  if (lane->flags & VS_FLAG_NOISE) f |= VS_DF_NOISE;
+  /* longest admissible period: T is an integer with (float)T <= t_hi */
+  d->tbound = (f & VS_DF_JITTER) ? (int)floorf(d->t_hi) : P;
+  if (d->tbound < P) d->tbound = P;
+  /* for an integer sample x: (float)x < par.DC  <=>  x < ceil(par.DC)   (fg:320, 329) */
+  d->thr = (lane->DC < 2147483000.0f) ? (int32_t)ceilf(lane->DC) : 2147483647;
+  /* VS_DF_FAST (vs_device.h): bounds under which the generator's short sequences equal the
+   * general ones.  Largest admissible amplitude: (float)1.8*amp with shimmer (fg:306), amp
+   * without; the rising flank reaches ceil(Amplitude), the falling one Amplitude*(1 - 2*Knew)
+   * with Knew <= K*(1 + Kvar) (fg:325). */
+  {
+    const double amax = (f & VS_DF_SHIMMER) ? (double)d->a_hi : (double)lane->amp;
+    const double kmax = (double)lane->K * (1.0 + (double)lane->Kvar) * 1.000001;
+    const int tmin = (f & VS_DF_JITTER) ? (int)ceilf(d->t_lo) : P; /* rejection keeps (float)T >= t_lo */
+    const bool in_short = amax <= 32767.0 && (2.0 * kmax - 1.0) * amax <= 32767.0 && lane->DC <= 32767.0f;
+    if (in_short && d->T2 >= 4 && 2 * d->T2 + VS_TRASH_ROWS <= tmin) f |= VS_DF_FAST;
+  }
+  d->flags = f;
+  d->key0 = (uint32_t)lane->seed;
+  d->key1 = (uint32_t)(lane->seed >> 32);
+  d->row = row;
+  d->out_snr = lane->out_snr;
+  {
+    /* milisec1 = (int)(header.nSamplesPerSec * 0.001/2.0)*2; Lframe = 50*milisec1 (vowel_new.c:361-363) */
+    const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
+    const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
+    d->Lframe = 50 * milisec1;
+  }
+  if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED; /* fs < 2000: zero-length frames */
+  d->okey0 = (uint32_t)lane->out_seed;
+  d->okey1 = (uint32_t)(lane->out_seed >> 32);
+  return VS_OK;
+}
+
+/* cos(PI*k/T2) with PI the reference's macro 4.0*atan(1.0) (flowgen_shimmer.c:39), which
+ * expands textually: PI*i/T2 == ((4.0*atan(1.0))*i)/T2 */
+void vs_cos_row(int T2, double *row)
+{
+  for (int k = 0; k < T2; k++) row[k] = cos(4.0 * atan(1.0) * k / T2);
+}
+
+/* Ring capacity in samples per lane and the super-step threshold that goes with it.
+ *
+ * A lane joins a generator round when its next cycle is certain to fit (fill + tbound <= slots)
+ * and takes part in a filter super-step when it holds VS_SS samples, so VS_SS + max(tbound) is
+ * the minimum.  More room lets lanes with long periods sit rounds out while the others catch
+ * up, which keeps both the rounds and the super-steps well attended; the policy table below
+ * comes from replaying real period sequences through the scheduler.
+ * The default keeps four 64-lane workgroups resident per CU (160 KiB LDS / 4). */
+int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request, double depth)
+{
+  const int hard_limit = ((VS_LDS_LIMIT - 16 * 1024) / (group_lanes * 2) / VS_SS) * VS_SS; /* keeps 16 KiB for cos rows */
+  /* one super-step + the longest cycle + the slots a trip may run past the cycle */
+  const int need = ((VS_SS + tmax + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
+  if (need > hard_limit) return VS_ERR_UNSUPPORTED;
+  if (cap <= 0) cap = 288; /* (288 + 8) rows * 128 B = 37 KiB + cos rows + sync words: four workgroups per CU */
+  cap = (cap / VS_SS) * VS_SS;
+  if (cap > hard_limit) cap = hard_limit;
+  int want = ((VS_SS + (int)(depth * tmax) + VS_SS - 1) / VS_SS) * VS_SS;
+  if (want < 192) want = 192;
+  int c = want < cap ? want : cap;
+  if (request > 0) c = cap; /* vs_tuning.ring_slots: the capacity itself, clamped to what fits */
+  if (c < need) c = need;
+  const double rho = (double)(c - VS_SS) / (double)tmax;
+  int thr = 32;                 /* half the live lanes */
+  if (rho >= 1.65) thr = 64;    /* all of them */
+  else if (rho >= 1.45) thr = 58;
+  else if (rho >= 1.33) thr = 48;
+  *slots = c;
+  if (ready_min) *ready_min = thr;
+  return VS_OK;
+}
+
+/* a ring of 64 columns (one utterance per lane of a wavefront) */
+int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min)
+{
+  return vs_ring_policy_for(VS_WAVE, tmax, cap, slots, ready_min, 0, 1.7);
+}
+
+/* Ring capacity for periods up to tmax: the 64-column ring if it can take them, else the narrow one
+ * (VS_NARROW_LANES columns, four times the slots in the same LDS). */
+int vs_ring_slots_for(int tmax, int *slots)
+{
+  int rc = vs_ring_policy_for(VS_WAVE, tmax, 0, slots, NULL, 0, 1.7);
+  if (rc == VS_ERR_UNSUPPORTED) rc = vs_ring_policy_for(VS_NARROW_LANES, tmax, 0, slots, NULL, 0, 1.7);
+  return rc;
+}
+
+/* filter-only lane record: gain, pre-emphasis, coefficients, row, vowel -n fields; everything
+ * of the source left zero.  Only the fields the reference's vowel reads are validated, so any
+ * sample rate goes (vowel_new.c:196-205 checks the format tag and the bit depth only). */
+int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
+{
+  if (!(lane->pre_emphasis >= 0.0 && lane->pre_emphasis <= 1.0)) return VS_ERR_RANGE; /* vw:127 */
+  if (!(lane->gain >= 1)) return VS_ERR_RANGE;                                        /* vw:132 */
+  double A[VS_MAX_NCOEF];
+  if (lane->vowel == VS_VOWEL_CUSTOM) {
+    int order = 0;
+    const int rc = vs_lane_order(lane, &order);
+    if (rc != VS_OK) return rc;
+    for (int j = 0; j <= order; j++)
+      if (!isfinite(lane->A[j])) return VS_ERR_RANGE;
+    if (lane->A[0] != 1.0) return VS_ERR_RANGE;
+  }
+  {
+    const int rc = vs_lane_taps(lane, A);
+    if (rc != VS_OK) return (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') ? VS_ERR_UNSUPPORTED : VS_ERR_RANGE;
+  }
+  if (lane->fs <= 0) return VS_ERR_RANGE;
+  memset(d, 0, sizeof(*d));
+  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j];
+  d->gain = (double)lane->gain;
+  d->pre = (double)lane->pre_emphasis;
+  d->row = row;
+  d->out_snr = lane->out_snr;
+  {
+    const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
+    const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
+    d->Lframe = 50 * milisec1; /* vowel_new.c:361-363 */
+  }
+  if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED;
+  d->okey0 = (uint32_t)lane->out_seed;
+  d->okey1 = (uint32_t)(lane->out_seed >> 32);
+  return VS_OK;
+}
+
+/* expansion of the lane records: independent per lane, so large batches are cut over a few host
+ * threads (65536 lanes: 38 ms on one core, the kernel itself takes under 3 ms) */
+typedef struct ExpandJob {
+  const vs_lane *lanes;
+  VsDevLane *dl;
+  size_t lo, hi;
+  int filter_only;
+  int rc;          /* first failure in [lo, hi) */
+  size_t bad;      /* ... and the lane it belongs to */
+} ExpandJob;
+
+static void *expand_range(void *arg)
+{
+  ExpandJob *j = (ExpandJob *)arg;
+  j->rc = VS_OK;
+  for (size_t l = j->lo; l < j->hi; l++) {
+    const int rc = j->filter_only ? vs_expand_filter_lane(&j->lanes[l], (int32_t)l, &j->dl[l])
+                                  : vs_expand_lane(&j->lanes[l], (int32_t)l, &j->dl[l]);
+    if (rc != VS_OK) {
+      j->rc = rc;
+      j->bad = l;
+      break;
+    }
+  }
+  return NULL;
+}
+
+int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only)
+{
+  long nt = 1;
+  if (n_lanes >= 8192) {
+    nt = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nt > 8) nt = 8;
+    if (nt < 1) nt = 1;
+  }
+  ExpandJob jobs[8];
+  pthread_t th[8];
+  const size_t per = (n_lanes + (size_t)nt - 1) / (size_t)nt;
+  int started = 0, n_jobs = 0;
+  for (long t = 0; t < nt; t++) {
+    const size_t lo = (size_t)t * per, hi = (lo + per < n_lanes) ? lo + per : n_lanes;
+    if (lo >= hi) break;
+    jobs[n_jobs].lanes = lanes;
+    jobs[n_jobs].dl = dl;
+    jobs[n_jobs].lo = lo;
+    jobs[n_jobs].hi = hi;
+    jobs[n_jobs].filter_only = filter_only;
+    jobs[n_jobs].rc = VS_OK;
+    jobs[n_jobs].bad = 0;
+    n_jobs++;
+  }
+  /* the last range runs on this thread; a thread that cannot be started is run here too */
+  for (int t = 0; t + 1 < n_jobs; t++) {
+    if (pthread_create(&th[t], NULL, expand_range, &jobs[t]) != 0) break;
+    started++;
+  }
+  for (int t = started; t < n_jobs; t++) expand_range(&jobs[t]);
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  for (int t = 0; t < n_jobs; t++) /* the failure of the lowest lane: the same answer whatever the thread count */
+    if (jobs[t].rc != VS_OK) return jobs[t].rc;
+  return VS_OK;
+}
+
+/* Wavefronts are formed from lanes with similar periods: stable order by (P, T2, flags).  A merge sort
+ * of lane indices (stable by construction), then one pass that moves the records. */
+static int lane_before(const VsDevLane *a, const VsDevLane *b)
+{
+  if (a->P != b->P) return a->P < b->P;
+  if (a->T2 != b->T2) return a->T2 < b->T2;
+  return a->flags < b->flags;
+}
+
+int vs_sort_lanes(VsDevLane **pdl, size_t n)
+{
+  VsDevLane *dl = *pdl;
+  uint32_t *idx = (uint32_t *)malloc(n * sizeof(uint32_t)), *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
+  VsDevLane *sorted = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+  if (!idx || !tmp || !sorted) {
+    free(idx);
+    free(tmp);
+    free(sorted);
+    return VS_ERR_NOMEM;
+  }
+  for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+  for (size_t w = 1; w < n; w *= 2) {
+    for (size_t lo = 0; lo < n; lo += 2 * w) {
+      const size_t mid = (lo + w < n) ? lo + w : n, hi = (lo + 2 * w < n) ? lo + 2 * w : n;
+      size_t a = lo, b = mid, o = lo;
+      while (a < mid && b < hi) tmp[o++] = lane_before(&dl[idx[b]], &dl[idx[a]]) ? idx[b++] : idx[a++]; /* ties: the left run first */
+      while (a < mid) tmp[o++] = idx[a++];
+      while (b < hi) tmp[o++] = idx[b++];
+    }
+    uint32_t *sw = idx;
+    idx = tmp;
+    tmp = sw;
+  }
+  for (size_t i = 0; i < n; i++) sorted[i] = dl[idx[i]];
+  free(idx);
+  free(tmp);
+  free(dl);
+  *pdl = sorted;
+  return VS_OK;
+}
+

@@ -1,0 +1,35 @@
+/*
+ * vs_planhost.h -- the device-free half of plan creation (csrc/vs_planhost.c), shared with vs_api.c.
+ */
+#ifndef VS_PLANHOST_H
+#define VS_PLANHOST_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/voice_synth.h"
+#include "vs_device.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* A[0..40] of the lane's filter: the table or the explicit set, zeros behind its order */
+int vs_lane_taps(const vs_lane *lane, double *A);
+bool vs_lane_is_wide(const vs_lane *lane);
+/* one lane -> the record the kernels read (validated); the filter-only form fills what vowel reads */
+int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
+int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
+/* all lanes, cut over up to 8 host threads for batches >= 8192; the failure of the lowest lane wins */
+int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only);
+void vs_cos_row(int T2, double *row);
+/* ring capacity (slots per utterance) and super-step threshold for periods up to tmax */
+int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request, double depth);
+int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min);
+int vs_ring_slots_for(int tmax, int *slots);
+/* stable order by (P, T2, flags); *pdl is replaced by the sorted array */
+int vs_sort_lanes(VsDevLane **pdl, size_t n);
+#ifdef __cplusplus
+}
+#endif
+#endif
