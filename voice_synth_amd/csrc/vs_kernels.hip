@@ -279,9 +279,26 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  * and the filter runs.  Spins are bounded (args.spin_limit polls, then the error word of the launch
  * is set and the wavefront leaves) so that a protocol bug cannot hang the device.
  */
-#ifndef VS_POLL_SLEEP
-#define VS_POLL_SLEEP 32 /* s_sleep units of 64 cycles between polls: a polling wave takes issue slots from the working one (A/B: 1, 2, 8, 32 -- 32 best by ~2 %) */
+/* s_sleep units of 64 cycles between two polls of a waiting wavefront.  A polling wavefront takes issue slots from the
+ * working ones, a sleeping one reacts late.  Two roles on a full grid (BASELINE config 5): 32 (A/B 1, 2, 8, 32: best by
+ * ~2 %; 8 is 1.2 % slower).  Three roles: 8 -- each wavefront has half the work per sample, hand-offs are twice as
+ * frequent, and a late reaction costs more than the polls (config 3: 2.81-2.86 against 2.88-2.91 ms at 32, four and
+ * five same-box repetitions; 4 .. 16 are alike; profiles/r04_poll_sleep_ab.txt).  Half-filled chips do not care.
+ * -DVS_POLL_SLEEP=n sets both (A/B builds). */
+#ifdef VS_POLL_SLEEP
+#define VS_POLL_SLEEP_2 VS_POLL_SLEEP
+#define VS_POLL_SLEEP_3 VS_POLL_SLEEP
+#else
+#define VS_POLL_SLEEP_2 32
+#define VS_POLL_SLEEP_3 8
 #endif
+/* (s_sleep takes an immediate: one call site per value) */
+template <bool THREE>
+__device__ __forceinline__ void vs_poll_sleep()
+{
+  if (THREE) __builtin_amdgcn_s_sleep(VS_POLL_SLEEP_3);
+  else __builtin_amdgcn_s_sleep(VS_POLL_SLEEP_2);
+}
 
 /* what every role of a group needs to find its lane, its ring and its progress words */
 struct VsGroup {
@@ -337,7 +354,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
     int taken = 0;
     if (SPLIT) taken = __hip_atomic_load(&g.ord.otak[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (!dirty && !__any((n_seen != prev_seen) || (taken != prev_taken))) {
-      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      vs_poll_sleep<SPLIT>();
       VS_DIAG_ADD(dg, 6)
       if (++spins > args.spin_limit) {
         if (args.err && lane == 0) atomicOr(args.err, 1);
@@ -372,7 +389,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
       spins = 0;
       dirty = true;
     } else {
-      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      vs_poll_sleep<SPLIT>();
       VS_DIAG_ADD(dg, 6)
       if (++spins > args.spin_limit) {
         if (args.err && lane == 0) atomicOr(args.err, 1);
@@ -443,7 +460,7 @@ __device__ __forceinline__ void vs_noise_wave(const VsKernelArgs &args, const Vs
       spins = 0;
       VS_DIAG_ADD(dg, 4)
     } else {
-      __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+      vs_poll_sleep<true>();
       VS_DIAG_ADD(dg, 6)
       if (++spins > args.spin_limit) {
         if (args.err && lane == 0) atomicOr(args.err, 4);
@@ -519,7 +536,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
 #endif
         const bool ready = !valid || (g_seen - n >= VS_SS) || (g_seen >= N);
         if (__all(ready)) break;
-        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+        vs_poll_sleep<!PARTIAL>();
         VS_DIAG_ADD(dg, 6)
         if (polls > args.spin_limit) {
           if (args.err && lane == 0) atomicOr(args.err, 2);
@@ -616,7 +633,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
         spins = 0;
         VS_DIAG_ADD(dg, 0)
       } else {
-        __builtin_amdgcn_s_sleep(VS_POLL_SLEEP);
+        vs_poll_sleep<!PARTIAL>();
         VS_DIAG_ADD(dg, 6)
         if (++spins > args.spin_limit) {
           if (args.err && lane == 0) atomicOr(args.err, 2);
