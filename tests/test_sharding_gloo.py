@@ -168,3 +168,14 @@ def test_watchdog_stamps(tmp_path):
     mp.spawn(_worker_phases, args=(1, _free_port(), str(tmp_path), "silent_phase"), nprocs=1, join=True)
     r = json.load(open(tmp_path / "r0.json"))
     assert r["early"] is None and r["after_tick"] is None and r["late"] == ["silent", 0] and r["left"] is None
+
+
+def test_pipelined_gather_eight_ranks(tmp_path):
+    """the world size the driver's scaling run ends at: eight ranks, 37 lanes (5 + 5 + 5 + 5 + 5 + 4 + 4 + 4), chunks of
+    2 -- the root posts three rounds of receives, the peers with four lanes sit the third one out"""
+    out = str(tmp_path / "pipelined8.npy")
+    mp.spawn(_worker_pipelined, args=(8, _free_port(), out, 37, 2), nprocs=8, join=True)
+    got = np.load(out)
+    specs, fs, dur, _ = configs.config_specs(3, 37)
+    lanes, d = vs.lanes_from_specs(specs)
+    assert np.array_equal(got, po.synth(lanes, 1500, threads=2))
