@@ -584,6 +584,9 @@ def main():
         if rank == 0 and isinstance(extra.get("config4"), dict):
             extra["config4"]["ranks_seen"] = ranks_seen
             extra["config4"]["distinct_devices"] = distinct_devices
+            if isinstance(extra["config4"].get("gather"), dict):   # whoever reads the gather figures sees who exchanged
+                extra["config4"]["gather"]["distinct_devices"] = distinct_devices
+                extra["config4"]["gather"]["devices"] = [r_["pci_bus_id"] for r_ in ranks_seen]
     leg_done.set()
     emit()
 

@@ -124,4 +124,5 @@ def test_bench_three_ranks_rehearsal_with_the_gather_leg():
     assert c4["utterances_per_gpu"] == 334       # rank 0's block of 1000 over 3
     g = c4["gather"]
     assert g["backend"] == "gloo" and g["overlapped"] is True and g["equals_unoverlapped_gather"] is True
+    assert g["distinct_devices"] == 1 and len(g["devices"]) == 3      # a rehearsal: three ranks, one device
     assert g["bytes_into_rank0"] == (1000 - 334) * 44100 * 2 and c4["value_with_gather"] > 0
