@@ -156,6 +156,15 @@ def test_which_fused_kernel_a_plan_takes(engine):
     assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 3>"
     assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 3>"   # a chunk of the delivery pipelines
     assert kernel(2, 1024) == "vs_synth_ws_kernel<0, true, 2>"
+    # ... over rings of 2.4 of the longest cycle where at most two groups share a CU, 1.7 (capped by the LDS) on full grids
+    def slots(cfg, n):
+        specs, fs, dur, _ = configs.config_specs(cfg, n)
+        lanes, d = vs.lanes_from_specs(specs)
+        plan = engine.plan(lanes, vs.num_samples(fs, d))
+        r = plan.info()["ring_slots"]
+        plan.close()
+        return r
+    assert slots(4, 32768) == 552 and slots(3, 16384) == 408 and slots(3, 65536) == 288
 
 
 def test_mixed_batch_every_option_combination(engine):
