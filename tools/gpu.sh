@@ -14,6 +14,7 @@
 #   tools/gpu.sh sweep <roles> [config] [lanes] generator round-start knobs
 #   tools/gpu.sh diag                           phase breakdown from the diagnostic build
 #   tools/gpu.sh full <tag>                     the round's evidence pass (copy the summaries into profiles/)
+#   tools/gpu.sh configs <tag>                  bench.py --config 2 / 4 / 5 under rocprofv3 --kernel-trace --stats
 # Steps may be chained:  tools/gpu.sh test -- ab default r2 -- bench
 # Boxes differ by up to 10 % in sustained clock, so variants are only ever compared within one call.
 set -o pipefail
@@ -100,6 +101,14 @@ run_step() {
       run_step sq config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
       run_step bench || return 1
       cp gpurun_out/bench.json gpurun_out/${tag}_bench_n1.json ;;
+    configs)
+      # the other BASELINE configurations under rocprofv3 --kernel-trace --stats:  tools/gpu.sh configs <tag>
+      local tag=${1:-r04}
+      for c in 2 4 5; do
+        run_step prof ${tag}_config$c --config $c --no-cpu-baseline > /dev/null || return 1
+        cp "$(find gpurun_out/prof_${tag}_config$c -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_config${c}_kernel_stats.csv
+        cp gpurun_out/prof_${tag}_config$c.json gpurun_out/${tag}_config${c}_bench.json
+      done ;;
     *) echo "unknown step $step"; return 2 ;;
   esac
 }
