@@ -324,10 +324,14 @@ int vs_node_set_arith(vs_node *node, int arith);
 int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *lo, size_t *hi);
 /* How vs_node_synth_gather moves a finished chunk into the root's memory.
  *   VS_NODE_TRANSPORT_PEER (default): peer DMA, one copy stream per shard.
- *   VS_NODE_TRANSPORT_RCCL: ncclSend / ncclRecv on ONE RCCL communicator over the node's devices,
+ *   VS_NODE_TRANSPORT_RCCL (EXPERIMENTAL until a multi-GPU node has run it: what one GPU can exercise -- the
+ *     communicator, the all-or-nothing start, the abort path -- is tested; a send and a receive between two devices
+ *     are not): ncclSend / ncclRecv on ONE RCCL communicator over the node's devices,
  *     created here and owned by the node (librccl is opened with dlopen at this call).  Needs every
  *     shard on a device of its own (VS_ERR_UNSUPPORTED otherwise, or when librccl is not there) and a
  *     packed root buffer (root_pitch == n_samples).
+ *     The exchange is all or nothing (every shard prepares all of its chunks before anybody enqueues anything); a
+ *     failure behind that point aborts the communicators (ncclCommAbort) and leaves the node on the peer transport.
  * vs_node_link(): how shard's PCM reaches the root -- VS_NODE_LINK_SELF (same device, in place),
  * _PEER (peer DMA), _STAGED (no peer access between the two devices: the copies go through host
  * memory), _RCCL.  vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call. */
