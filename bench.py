@@ -64,7 +64,7 @@ GATHER_CHUNK = 16384            # utterances per chunk of the pipelined gather
 SUSTAINED_S = 2.0                # back-to-back launches of the same plan for at least this long (`sustained`)
 # the config-4 block runs under a watchdog that knows its phases: a phase that shows no progress for this long is a
 # stalled exchange (bytes moved scale the allowance: 60 s + 1 s per GB into rank 0)
-PHASE_DEADLINE_S = 60
+PHASE_DEADLINE_S = int(os.environ.get("VS_BENCH_PHASE_DEADLINE_S", "60"))   # (the variable: tests of the watchdog only)
 TEARDOWN_DEADLINE_S = 60        # nor may the closing barrier hold the process once the line is printed
 
 
@@ -78,6 +78,7 @@ def parse_args():
     ap.add_argument("--arith", choices=["exact", "fma"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the configs 2 / 4-shard / 5 launches behind the timed region")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the config-4 block (262144 x 44100 over the ranks)")
     ap.add_argument("--config4-lanes", type=int, default=0, help="N > 1: utterances of the config-4 block (default 262144; tests)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target CPU-baseline run time")
@@ -252,6 +253,51 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
     return out
 
 
+def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=5, warm=2):
+    """One BASELINE configuration outside the timed region: plan, `warm` untimed launches, then HIP events on the
+    launch stream around each of `launches` launches, in both arithmetic contracts.  Returns one record per contract:
+    {workload, kernel, arith, kernel_ms_avg, kernel_ms_min, roofline_frac, ...}."""
+    import torch
+
+    import voice_synth_amd as vs
+    from voice_synth_amd import configs
+
+    specs, fs, dur, label = configs.config_specs(cfg_i, n_lanes, lane0=0)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    pitch = (ns + 7) & ~7
+    plan = eng.plan(lanes, ns)
+    out = torch.empty((n_lanes, pitch), dtype=torch.int16, device=dev)
+    recs = []
+    try:
+        other = vs.VS_ARITH_FMA if arith_first == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
+        for ar in (arith_first, other):
+            eng.set_arith(ar)
+            for _ in range(warm):
+                plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+            torch.cuda.synchronize(dev)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+            for a, b in ev:
+                a.record(stream)
+                plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+                b.record(stream)
+            torch.cuda.synchronize(dev)
+            plan.status()
+            ms = sorted(a.elapsed_time(b) for a, b in ev)
+            avg = sum(ms) / len(ms)
+            recs.append({"workload": label, "baseline_config_index": cfg_i - 1, "utterances": n_lanes, "samples_per_utterance": ns,
+                         "arith": "exact" if ar == vs.VS_ARITH_EXACT else "fma",
+                         "kernel": plan.kernel_name(vs.VS_KIND_SYNTH), "launches": launches,
+                         "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(ms[0], 4),
+                         "Msamples/s": round(n_lanes * ns / (avg * 1e-3) / 1e6, 1),
+                         "roofline_frac": round(ALGO_BYTES_PER_SAMPLE * n_lanes * ns / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+    finally:
+        del out
+        plan.close()
+        torch.cuda.empty_cache()
+    return recs
+
+
 def _profile_record(name, key):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -277,15 +323,42 @@ def _profile_provenance(traffic_rec, valu_rec):
     return out
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process
+    (`python -m torch.distributed.run`, one rank per GPU), relay its output unchanged and leave with its exit code.
+    Called before this process has imported torch or touched the GPU; nothing is exec'ed over a running program."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this image
+    env["VS_BENCH_SELF_LAUNCHED"] = "1"
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, env=env)      # inherits stdout / stderr: rank 0's JSON line arrives as it is
+    try:
+        rc = child.wait()
+    except KeyboardInterrupt:  # pragma: no cover
+        child.terminate()
+        rc = child.wait()
+    return rc if rc >= 0 else 128 - rc
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
-                     % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
     import torch
@@ -421,6 +494,20 @@ def main():
     other_ms = sum(other_kern) / len(other_kern)
     eng.set_arith(arith)
 
+    # ---- the other BASELINE configurations, outside the timed region (N = 1 only; at N > 1 the config-4 block below
+    # is the second workload): configs 2, 4 (one GPU's shard of the 8-GPU cut) and 5, each launched a few times with
+    # HIP events around every launch, in both arithmetic contracts -- so that the driver's line carries every
+    # configuration's kernel time, not only the headline's ----
+    other_configs = None
+    if world == 1 and rank == 0 and not args.no_other_configs and args.config == 3 and not args.lanes:
+        other_configs = []
+        for cfg_i, n_l in ((2, 1024), (4, 262144 // 8), (5, 65536)):
+            try:
+                other_configs += measure_config(eng, dev, stream, cfg_i, n_l, arith)
+            except Exception as exc:  # pragma: no cover - reported in the line
+                other_configs.append({"baseline_config_index": cfg_i - 1, "error": "%s: %s" % (type(exc).__name__, exc)})
+        eng.set_arith(arith)
+
     result = None
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e9
@@ -505,6 +592,7 @@ def main():
                             "kernel_ms_median": round(other_kern[len(other_kern) // 2], 4),
                             "kernel_ms_min": round(other_kern[0], 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
+            "other_configs": other_configs,
             "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
                      "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
                              "sort, cos rows; allocation + upload + wait.  Outside every timed region."},
@@ -559,8 +647,14 @@ def main():
                     if store.check([ABORT_KEY]):
                         if abort_seen is None or abort_seen[0] != cur:
                             abort_seen = (cur, time.monotonic(), store.get(ABORT_KEY).decode(errors="replace"))
-                        elif time.monotonic() - abort_seen[1] > ABORT_GRACE_S:
+                        # the grace runs from the last sign of life of THIS rank's phase, not from the moment the
+                        # key appeared: a rank that is still working towards the phase's agreement (building its
+                        # chunk plans, say) gets there and leaves with everybody else, exit code 0; only one that
+                        # sits in a collective the failed rank will never join shows no progress
+                        elif time.monotonic() - max(abort_seen[1], phases.last_tick()) > ABORT_GRACE_S:
                             why = "phase '%s' abandoned: %s" % (cur, abort_seen[2])
+                    else:
+                        abort_seen = None      # the phase was agreed on and the key cleared (run_phase)
                 except Exception:  # pragma: no cover - the store went away with its rank
                     pass
             if why:
@@ -590,18 +684,33 @@ def main():
     leg_done.set()
     emit()
 
+    step = ["plan.close"]
     if use_dist:
-        # the line is out and this rank's work is done; a peer that left early must not hold the others in
-        # the closing barrier for ever (that peer's own exit code is what fails the job)
+        # The line is out and this rank's work is done, but a teardown step that hangs (a closing barrier a peer
+        # never joins, a device that does not answer) must not hold the process for ever -- and must not read as
+        # a success either: the deadline leaves with a NON-ZERO code and names the step.  Only when a peer has SAID
+        # that it failed (the abort key in the job's store: that peer's own exit code fails the job) is a barrier
+        # that never completes the expected outcome.
         def leave():
             time.sleep(TEARDOWN_DEADLINE_S)
-            os._exit(0)
+            peer_failed = False
+            try:
+                peer_failed = store is not None and store.check([ABORT_KEY])
+            except Exception:  # pragma: no cover - the store went away with its rank
+                peer_failed = step[0] in ("barrier", "destroy_process_group")
+            sys.stderr.write("bench.py: rank %d: teardown step '%s' still running after %d s%s\n"
+                             % (rank, step[0], TEARDOWN_DEADLINE_S, " (a peer reported a failure)" if peer_failed else ""))
+            sys.stderr.flush()
+            os._exit(0 if (peer_failed and step[0] in ("barrier", "destroy_process_group")) else 4)
         threading.Thread(target=leave, daemon=True).start()
 
     plan.close()
+    step[0] = "eng.close"
     eng.close()
     if use_dist:
+        step[0] = "barrier"
         dist.barrier()
+        step[0] = "destroy_process_group"
         dist.destroy_process_group()
 
 
@@ -630,6 +739,10 @@ class Phases:
         with self._lock:
             self._name = None
 
+    def last_tick(self):
+        with self._lock:
+            return self._t
+
     def stalled(self):
         with self._lock:
             if self._name is not None and time.monotonic() - self._t > self._allow:
@@ -642,8 +755,8 @@ class Phases:
 
 
 ABORT_KEY = "vs_bench_abort"
-ABORT_GRACE_S = 10   # a rank that failed says so in the job's store; peers that are still inside the phase's own
-                     # collectives this long afterwards will never leave them by themselves
+ABORT_GRACE_S = 10   # a rank that failed says so in the job's store; peers that have shown no progress (Phases.tick)
+                     # for this long afterwards sit in a collective they will never leave by themselves
 
 
 def _job_store():
@@ -678,6 +791,14 @@ def run_phase(phases, name, allow_s, fn, rank, dev):
     ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     phases.leave()
+    if err is not None:
+        # every rank has taken part in the agreement: the key has done its job (a later phase starts clean)
+        st = _job_store()
+        if st is not None:
+            try:
+                st.delete_key(ABORT_KEY)
+            except Exception:  # pragma: no cover
+                pass
     if int(ok.item()) == 0:
         raise PhaseFailed("phase '%s' failed on %s" % (name, ("this rank (%d): %s: %s" % (rank, type(err).__name__, err)) if err
                                                         else "another rank (see its stderr)"))
@@ -715,6 +836,8 @@ def config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases):
     allow = PHASE_DEADLINE_S + nbytes / 1e9       # 60 s + 1 s per GB that has to reach rank 0
 
     def timed_steps():
+        if os.environ.get("VS_BENCH_FAULT") == "stall_rank1" and rank == 1:
+            time.sleep(10 ** 6)      # tests only: a rank that never reaches the phase's collectives
         plan = eng.plan(lanes, ns)
         kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
         out = torch.empty((per, pitch), dtype=torch.int16, device=dev)
@@ -765,8 +888,11 @@ def config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases):
         if rank == 0 and torch.cuda.mem_get_info(dev)[0] <= need:
             raise MemoryError("rank 0 has no room for %d bytes of gathered PCM" % need)
         state["pg"] = PipelinedGather(total, ns, GATHER_CHUNK, dev)
-        state["plans"] = [eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), ns)
-                          for a_, b_ in state["pg"].edges]
+        phases.tick()
+        state["plans"] = []
+        for a_, b_ in state["pg"].edges:
+            state["plans"].append(eng.plan((vs.Lane * (b_ - a_)).from_buffer(lanes, a_ * vs.C.sizeof(vs.Lane)), ns))
+            phases.tick()
 
     try:
         phase("gather set-up (buffers, chunk plans)", PHASE_DEADLINE_S, gather_setup)

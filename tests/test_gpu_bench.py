@@ -126,3 +126,51 @@ def test_bench_three_ranks_rehearsal_with_the_gather_leg():
     assert g["backend"] == "gloo" and g["overlapped"] is True and g["equals_unoverlapped_gather"] is True
     assert g["distinct_devices"] == 1 and len(g["devices"]) == 3      # a rehearsal: three ranks, one device
     assert g["bytes_into_rank0"] == (1000 - 334) * 44100 * 2 and c4["value_with_gather"] > 0
+
+
+def test_bench_plain_invocation_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` WITHOUT a launcher (the shape of the driver's N = 1 command): bench.py starts
+    `python -m torch.distributed.run` as a child process before anything touches the GPU, relays rank 0's line and
+    leaves with the child's exit code.  Rehearsal: both ranks share device 0 over gloo, config-4 block with its gather."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lanes", "4096",
+           "--config4-lanes", "1000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=900, env=dict(env, VS_BENCH_REHEARSAL="2"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert b"without a launcher" in out.stderr
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # ONE line: rank 0's, relayed unchanged
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["ranks_seen"]) == 2 and [x["rank"] for x in d["ranks_seen"]] == [0, 1]
+    assert d["steps"] == 2 and "error" not in d["config4"], d["config4"]
+    assert d["config4"]["gather"]["equals_unoverlapped_gather"] is True
+
+
+def test_bench_plain_invocation_propagates_the_watchdog_exit():
+    """a rank that never reaches a phase's collectives: the phase watchdog ends every rank with a non-zero code after
+    rank 0 has printed the line with what it has -- and the plain invocation leaves with a non-zero code too"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lanes", "4096",
+           "--config4-lanes", "1000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=900,
+                         env=dict(env, VS_BENCH_REHEARSAL="1", VS_BENCH_FAULT="stall_rank1", VS_BENCH_PHASE_DEADLINE_S="8"))
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "no progress" in d["config4"]["error"]
+
+
+def test_bench_line_carries_every_baseline_configuration():
+    """the default workload (config 3, full size) with the CPU legs switched off: `other_configs` holds configs 2,
+    4 (one GPU's shard) and 5 in both arithmetic contracts, each with its kernel, time and roofline fraction"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
+    oc = d["other_configs"]
+    assert [(r["baseline_config_index"], r["arith"]) for r in oc] == [(1, "exact"), (1, "fma"), (3, "exact"), (3, "fma"), (4, "exact"), (4, "fma")]
+    for r in oc:
+        assert "error" not in r and r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] >= r["kernel_ms_min"] > 0
+        assert abs(r["roofline_frac"] - 2 * r["utterances"] * r["samples_per_utterance"] / (r["kernel_ms_avg"] * 1e-3) / 8e12) < 2e-4
+    assert oc[2]["utterances"] == 32768 and oc[2]["samples_per_utterance"] == 44100

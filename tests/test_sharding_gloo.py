@@ -7,6 +7,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -179,3 +180,25 @@ def test_pipelined_gather_eight_ranks(tmp_path):
     specs, fs, dur, _ = configs.config_specs(3, 37)
     lanes, d = vs.lanes_from_specs(specs)
     assert np.array_equal(got, po.synth(lanes, 1500, threads=2))
+
+
+def test_plain_bench_invocation_starts_its_own_ranks_and_propagates_their_exit_code():
+    """`python bench.py --gpus 2` without a launcher starts `python -m torch.distributed.run` as a CHILD process before
+    it has imported torch; here (no GPU) both ranks fail at once, and the parent must leave with a non-zero code too --
+    not with the usage message of earlier rounds, and not with 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_bench.py runs the same path to the end")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, cwd=root, timeout=300, env=env)
+    err = out.stderr.decode(errors="replace")
+    assert out.returncode not in (0, None), err[-2000:]
+    assert "without a launcher" in err and "torch.distributed.run" in err and "--nproc-per-node 2" in err
+    assert "needs `python -m torch.distributed.run" not in err
+    # under a launcher with the wrong world size it still refuses
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, cwd=root, timeout=120,
+                         env=dict(env, WORLD_SIZE="3", RANK="0"))
+    assert out.returncode != 0 and b"WORLD_SIZE=3 but --gpus 2" in out.stderr
