@@ -598,8 +598,8 @@ int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
   }
   const int ws = p->wave_specialised && kind == VS_KIND_SYNTH && !p->d_opow;
   const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
-  if (ws)
-    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, pre1 ? "true" : "false", p->ws_roles);
+  if (ws) /* both arithmetic contracts have a pre-emphasis-1.0 instantiation of the wave-specialised kernels */
+    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, p->pre1 ? "true" : "false", p->ws_roles);
   else
     snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
              pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");

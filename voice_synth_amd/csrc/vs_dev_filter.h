@@ -61,8 +61,19 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
 
   /* results leave in chunks of 8 samples = one 16-byte store, as soon as a chunk is complete: 24
    * pending results would cost 24 registers (the three-role kernel runs at 168 per wavefront) */
+  /* EAGER (the branch-free super-steps of the wave-specialised kernels): a pair of results is clamped and packed as
+   * soon as its second sample is rounded, so a chunk in flight holds four packed words and at most one unpaired
+   * result instead of eight integers -- the three registers between 168 and a spill of the three-role kernel's
+   * pre-emphasis variants */
+  constexpr bool EAGER = PACKED && (WHOLE == 1);
+  uint32_t pk[4];
   auto put8 = [&](int k) {
-    if (whole) {
+    if (EAGER) {
+      vs_u32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pk[e];
+      if (store_ok) *(vs_u32x4 *)(orow + n + 8 * k) = v;
+    } else if (whole) {
       vs_u32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -146,6 +157,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         qlo = (olo > qlo) ? olo : qlo;
       }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
+      if (EAGER && (t & 1)) pk[(t & 7) >> 1] = vs_clamp_pack16(outv[t - 1], outv[t]);
       if ((t & 7) == 7) put8(t >> 3);
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
@@ -163,7 +175,13 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         outv[t] = vs_round2int(o);
       }
 #pragma unroll
-      for (int k = 0; k < VS_SS / 8; ++k) put8(k);
+      for (int k = 0; k < VS_SS / 8; ++k) {
+        if (EAGER) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pk[e] = vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+        }
+        put8(k);
+      }
     }
   }
 }

@@ -1091,7 +1091,8 @@ extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_sp
       if (three) fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 3>;
       else fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 2> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 2>;
     } else {
-      fn = three ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 2>;
+      if (three) fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, true, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 3>;
+      else fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, true, 2> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 2>;
     }
     /* lds_bytes arrives as the bytes of ONE group (ring + cos rows + progress words); args->ws_pairs
      * groups share a workgroup, args->ws_roles wavefronts serve each */
