@@ -459,12 +459,21 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(dev)
     e0.record(stream)
-    for _ in range(n_sus):
-        launch()
-    e1.record(stream)
-    torch.cuda.synchronize(dev)
+    n_block, n_done = n_sus, 0
+    while True:
+        # (the estimate above comes from the burst, whose first launches run on a cold clock: top up until the
+        # launches really span SUSTAINED_S -- one host wait per block, nothing else between the launches)
+        for _ in range(n_block):
+            launch()
+        n_done += n_block
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        sus_ms = e0.elapsed_time(e1)
+        if sus_ms >= SUSTAINED_S * 1e3 or n_done >= 40000:
+            break
+        n_block = int(max(10, (SUSTAINED_S * 1e3 - sus_ms) / (sus_ms / n_done) * 1.05 + 1))
+    n_sus = n_done
     plan.status()
-    sus_ms = e0.elapsed_time(e1)
     st = torch.tensor([sus_ms / n_sus], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(st, op=dist.ReduceOp.MAX)

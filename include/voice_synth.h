@@ -254,7 +254,12 @@ int vs_ctx_synchronize(vs_ctx *ctx);
 /* Waits for the context's stream, then reports the health word of the plan's launches:
  * VS_OK, or VS_ERR_INTERNAL if a device-side check failed (*flags, optional, gets the raw bits:
  * 1, 2, 4 = a bounded wait of the generator / filter / noise wavefront ran out, 8 = plan and kernel
- * disagree about the room for the cos rows).  The one-call conveniences below check it themselves. */
+ * disagree about the room for the cos rows).  The one-call conveniences below check it themselves.
+ * What such a launch has written is NOT the utterances (lanes whose check failed synthesise from whatever
+ * the LDS holds): every row of every launch of the plan since the last VS_OK status must be discarded.  The
+ * chunked paths (vs_synth_rows, vs_node_synth_gather, vs_node_synth_rows) read the status of a chunk only
+ * after it has been delivered, so rows a callback has already seen, or that already lie in the caller's
+ * buffer, are to be discarded as well when the call returns VS_ERR_INTERNAL. */
 int vs_plan_status(vs_plan *plan, int *flags);
 
 /* Host cost of vs_plan_create(): host_ms = validation, parameter expansion, sorting, cosine

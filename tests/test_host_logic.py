@@ -310,10 +310,24 @@ def test_profile_provenance_nulls_counters_of_another_tree(tmp_path):
     import shutil
     for d in provenance.SOURCE_DIRS:
         shutil.copytree(os.path.join(root, d), tmp_path / d)
+    shutil.copy(os.path.join(root, "Makefile"), tmp_path / "Makefile")      # HIPFLAGS are part of the hash
     assert provenance.kernel_sources_sha16(str(tmp_path)) == tree
+    # a comment or white space more does not orphan the PMC passes ...
     with open(tmp_path / "voice_synth_amd" / "csrc" / "vs_device.h", "a") as f:
-        f.write("\n")
+        f.write("\n/* a remark */   // and another\n")
+    assert provenance.kernel_sources_sha16(str(tmp_path)) == tree
+    assert provenance.all_sources_sha16(str(tmp_path)) != provenance.all_sources_sha16()
+    # ... a token more in the device code, in the plan policy or in the compiler flags does
+    with open(tmp_path / "voice_synth_amd" / "csrc" / "vs_device.h", "a") as f:
+        f.write("#define VS_ONE_MORE 1\n")
     assert provenance.kernel_sources_sha16(str(tmp_path)) != tree
+    shutil.copy(os.path.join(root, "voice_synth_amd", "csrc", "vs_device.h"), tmp_path / "voice_synth_amd" / "csrc" / "vs_device.h")
+    assert provenance.kernel_sources_sha16(str(tmp_path)) == tree
+    mk = open(tmp_path / "Makefile").read().replace("HIPFLAGS := -O3", "HIPFLAGS := -O2")
+    open(tmp_path / "Makefile", "w").write(mk)
+    assert provenance.kernel_sources_sha16(str(tmp_path)) != tree
+    # a string literal that looks like a comment is left alone
+    assert provenance.strip_comments('a = "/* not */ // one";  /* gone */ b') == 'a = "/* not */ // one"; b'
 
 
 def test_gather_bookkeeping_ragged_cuts_and_more_shards_than_chunks():

@@ -4,15 +4,21 @@ PMC passes (profiles/pmc_traffic.json, profiles/pmc_valu.json) are collected in 
 figures bench.py copies out of them are only true of the kernel that was shipped when they were taken.
 Two stamps tie them to the tree:
 
-  kernel_sources_sha16  sha256 (first 16 hex digits) over the sources everything under
-                        voice_synth_amd/csrc/ and include/ is built from.  Computable on the GPU box
-                        (the snapshot carries no .git), so it is what bench.py compares at run time.
+  kernel_sources_sha16  sha256 (first 16 hex digits) over what determines the device code AND how it is launched:
+                        csrc/vs_kernels.hip, vs_dev_*.h, vs_device.h, vs_tables.h (the kernels), vs_api.c,
+                        vs_planhost.[ch], vs_internal.h (the plan: ring depth, roles, thresholds), include/voice_synth.h
+                        and the Makefile's HIPFLAGS -- with comments and white space stripped, so that a
+                        comment-only edit does not orphan the PMC passes (round 4 had to re-take them for one).
+                        Computable on the GPU box (the snapshot carries no .git), so it is what bench.py
+                        compares at run time.  all_sources_sha16: the raw bytes of everything under csrc/ and
+                        include/, informational.
   profile_head          `git log -1 --format=%h -- voice_synth_amd/csrc include` (+ "-dirty") of the tree
                         the pass ran on.  Taken HERE, before the snapshot leaves (tools/gpurun.sh writes
                         build/git_head.txt, which travels), because the box has no git history.
 """
 import hashlib
 import os
+import re
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +26,45 @@ SOURCE_DIRS = ("voice_synth_amd/csrc", "include")
 SOURCE_EXT = (".hip", ".h", ".c")
 
 
+KERNEL_FILES = ("voice_synth_amd/csrc/vs_kernels.hip", "voice_synth_amd/csrc/vs_dev_primitives.h",
+                "voice_synth_amd/csrc/vs_dev_generator.h", "voice_synth_amd/csrc/vs_dev_filter.h",
+                "voice_synth_amd/csrc/vs_device.h", "voice_synth_amd/csrc/vs_tables.h", "voice_synth_amd/csrc/vs_api.c",
+                "voice_synth_amd/csrc/vs_planhost.c", "voice_synth_amd/csrc/vs_planhost.h",
+                "voice_synth_amd/csrc/vs_internal.h", "include/voice_synth.h")
+
+
+def strip_comments(text):
+    """C / C++ source without comments and with runs of white space collapsed (string and character
+    literals are left alone)"""
+    pat = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
+    text = pat.sub(lambda m: " " if m.group(0).startswith("/") else m.group(0), text)
+    return " ".join(text.split())
+
+
+def hipflags(root=ROOT):
+    try:
+        for line in open(os.path.join(root, "Makefile")):
+            if line.startswith("HIPFLAGS"):
+                return " ".join(line.split(":=", 1)[1].split())
+    except OSError:
+        pass
+    return ""
+
+
 def kernel_sources_sha16(root=ROOT):
+    h = hashlib.sha256()
+    for rel in KERNEL_FILES:
+        path = os.path.join(root, rel)
+        if not os.path.exists(path):
+            continue
+        h.update(rel.encode() + b"\0")
+        h.update(strip_comments(open(path, encoding="utf-8", errors="replace").read()).encode())
+        h.update(b"\0")
+    h.update(hipflags(root).encode())
+    return h.hexdigest()[:16]
+
+
+def all_sources_sha16(root=ROOT):
     h = hashlib.sha256()
     for d in SOURCE_DIRS:
         base = os.path.join(root, d)
@@ -56,7 +100,7 @@ def git_head(root=ROOT):
 
 
 def stamp():
-    return {"profile_head": git_head(), "kernel_sources_sha16": kernel_sources_sha16()}
+    return {"profile_head": git_head(), "kernel_sources_sha16": kernel_sources_sha16(), "all_sources_sha16": all_sources_sha16()}
 
 
 if __name__ == "__main__":

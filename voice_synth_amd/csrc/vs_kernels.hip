@@ -90,8 +90,10 @@ __device__ __forceinline__ void vs_stage_cos_rows(const VsDevLane *__restrict__ 
       /* Plan and kernel disagree about the room for the cos rows ("cannot happen"): like every other
        * one of those, it sets the launch's error word -- vs_plan_status() answers VS_ERR_INTERNAL -- and
        * the launch runs to its end: the lanes that are still pending keep row offset 0 and synthesise
-       * from whatever lies there (finite garbage: every loop bound of the generator is a lane constant or
-       * comes from the draws, none from the cos values), nothing is written outside the staged region. */
+       * from whatever lies there -- staged rows of other lanes, progress words, uninitialised LDS, possibly NaN or
+       * infinity: garbage, but harmless garbage (every loop bound of the generator is a lane constant or comes
+       * from the draws, none from the cos values; the conversions saturate), and nothing is written outside
+       * the staged region.  The caller discards the rows (include/voice_synth.h, vs_plan_status). */
       if (args.err && lane == 0) atomicOr(args.err, 8);
       break;
     }
@@ -258,7 +260,8 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
  *     Half-filled chips with glottal noise (BASELINE config 4 sharded over 8 GPUs: 512 groups on 1024 SIMDs; the
  *     16384-utterance chunks of the pipelines) take three roles too, laid out so that the filter wavefront -- the
  *     bound in exact arithmetic -- has a SIMD to itself and the two generator wavefronts share the next one
- *     (VS_WS_LAYOUT_SPREAD_2X3, vs_device.h; one group per workgroup: a SIMD per wavefront), over rings of 2.4 cycles.
+ *     (VS_WS_LAYOUT_SPREAD_2X3, vs_device.h: TWO groups per workgroup, the launcher refuses anything else; a grid of
+ *     at most one group per CU runs role-major with one group per workgroup, a SIMD per wavefront), over rings of 2.4 cycles.
  *
  * Hand-off (workgroup scope, LDS only), per lane l:
  *   gpub[l] = samples of l that are complete in the ring     (written by the generator / by the noise wavefront)

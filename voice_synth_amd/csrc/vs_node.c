@@ -85,7 +85,14 @@ struct vs_node {
   int transport;                      /* VS_NODE_TRANSPORT_* */
   VsRccl rccl;
   int n_comm;                         /* communicators made (0 or n_shards), RCCL transport only */
-  vs_nccl_comm comm[VS_NODE_MAX_SHARDS]; /* one per shard (rank = shard) */
+  vs_nccl_comm comm[VS_NODE_MAX_SHARDS]; /* one per shard (rank = shard); NULL once aborted */
+  /* every host call into RCCL on comm[s] -- the shard's ncclSend, the root's GroupStart .. GroupEnd, and the
+   * ncclCommAbort of a failing shard's thread -- is made under comm_m[s]: an abort can then never free a
+   * communicator another thread is inside of, and whoever comes after it finds NULL and stops */
+  pthread_mutex_t comm_m[VS_NODE_MAX_SHARDS];
+  bool comm_m_ready;
+  void *rccl_lib_aborted;             /* librccl of an aborted exchange: kept open until vs_node_destroy (its proxy
+                                         threads may still be winding down when the gather returns) */
   hipStream_t recv;                   /* on the root device: THE stream the root's receive groups are posted on */
   int last_rccl_error;
 };
@@ -97,6 +104,8 @@ int vs_node_create(const int *devices, int n_shards, vs_node **out)
   vs_node *nd = (vs_node *)calloc(1, sizeof(vs_node));
   if (!nd) return VS_ERR_NOMEM;
   nd->transport = VS_NODE_TRANSPORT_PEER;
+  for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) pthread_mutex_init(&nd->comm_m[s], NULL);
+  nd->comm_m_ready = true;
   int rc = VS_OK;
   for (int s = 0; s < n_shards && rc == VS_OK; s++) {
     vs_ctx *c = NULL;
@@ -137,14 +146,18 @@ int vs_node_create(const int *devices, int n_shards, vs_node **out)
   return VS_OK;
 }
 
-static void vs_node_drop_rccl(vs_node *nd)
+/* keep_lib: the exchange was ABORTED -- the library stays loaded until vs_node_destroy (ncclCommAbort returns
+ * while RCCL's proxy threads may still be running its code) */
+static void vs_node_drop_rccl(vs_node *nd, bool keep_lib)
 {
   for (int s = 0; s < nd->n_comm; s++) {
+    pthread_mutex_lock(&nd->comm_m[s]);
     if (nd->comm[s] && nd->rccl.CommDestroy) {
       (void)hipSetDevice(nd->device[s]);
       (void)nd->rccl.CommDestroy(nd->comm[s]);
     }
     nd->comm[s] = NULL;
+    pthread_mutex_unlock(&nd->comm_m[s]);
   }
   nd->n_comm = 0;
   if (nd->recv) {
@@ -152,7 +165,10 @@ static void vs_node_drop_rccl(vs_node *nd)
     (void)hipStreamDestroy(nd->recv);
     nd->recv = NULL;
   }
-  if (nd->rccl.lib) dlclose(nd->rccl.lib);
+  if (nd->rccl.lib) {
+    if (keep_lib && !nd->rccl_lib_aborted) nd->rccl_lib_aborted = nd->rccl.lib; /* one reference is enough to pin it */
+    else dlclose(nd->rccl.lib);
+  }
   memset(&nd->rccl, 0, sizeof(nd->rccl));
 }
 
@@ -161,7 +177,7 @@ int vs_node_set_transport(vs_node *nd, int transport)
   if (!nd || (transport != VS_NODE_TRANSPORT_PEER && transport != VS_NODE_TRANSPORT_RCCL)) return VS_ERR_ARG;
   if (transport == nd->transport) return VS_OK;
   if (transport == VS_NODE_TRANSPORT_PEER) {
-    vs_node_drop_rccl(nd);
+    vs_node_drop_rccl(nd, false);
     nd->transport = transport;
     memcpy(nd->link, nd->base_link, sizeof(nd->link));
     return VS_OK;
@@ -203,7 +219,7 @@ int vs_node_set_transport(vs_node *nd, int transport)
   *(void **)&R->GroupStart = dlsym(R->lib, "ncclGroupStart");
   *(void **)&R->GroupEnd = dlsym(R->lib, "ncclGroupEnd");
   if (!R->CommInitAll || !R->CommDestroy || !R->CommAbort || !R->Send || !R->Recv || !R->GroupStart || !R->GroupEnd) {
-    vs_node_drop_rccl(nd);
+    vs_node_drop_rccl(nd, false);
     return VS_ERR_UNSUPPORTED;
   }
   memset(nd->comm, 0, sizeof(nd->comm));
@@ -211,7 +227,7 @@ int vs_node_set_transport(vs_node *nd, int transport)
   if (e != 0) {
     nd->last_rccl_error = e;
     nd->n_comm = 0;
-    vs_node_drop_rccl(nd);
+    vs_node_drop_rccl(nd, false);
     return VS_ERR_HIP;
   }
   nd->n_comm = S;
@@ -220,7 +236,7 @@ int vs_node_set_transport(vs_node *nd, int transport)
   hipError_t he = hipSetDevice(nd->device[0]);
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&nd->recv, hipStreamNonBlocking);
   if (he != hipSuccess) {
-    vs_node_drop_rccl(nd);
+    vs_node_drop_rccl(nd, false);
     return VS_ERR_HIP;
   }
   nd->transport = transport;
@@ -239,7 +255,8 @@ int vs_node_last_rccl_error(const vs_node *nd) { return nd ? nd->last_rccl_error
 void vs_node_destroy(vs_node *nd)
 {
   if (!nd) return;
-  vs_node_drop_rccl(nd);
+  vs_node_drop_rccl(nd, false);
+  if (nd->rccl_lib_aborted) dlclose(nd->rccl_lib_aborted);
   for (int s = 0; s < nd->n_shards; s++) {
     (void)hipSetDevice(nd->device[s]);
     if (nd->compute[s]) (void)hipStreamDestroy(nd->compute[s]);
@@ -250,6 +267,8 @@ void vs_node_destroy(vs_node *nd)
     }
     vs_ctx_destroy(nd->ctx[s]);
   }
+  if (nd->comm_m_ready)
+    for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) pthread_mutex_destroy(&nd->comm_m[s]);
   free(nd);
 }
 
@@ -332,10 +351,14 @@ static void abort_exchange(vs_node *nd, GatherSync *sync)
   pthread_mutex_lock(&sync->abort_m);
   if (!atomic_exchange(&sync->aborted, true) && nd->transport == VS_NODE_TRANSPORT_RCCL) {
     for (int p = 0; p < nd->n_comm; p++) {
+      /* under the communicator's lock: no other thread is inside ncclSend / the root's receive group on it,
+       * and whoever takes the lock next finds NULL */
+      pthread_mutex_lock(&nd->comm_m[p]);
       if (nd->comm[p]) {
         (void)nd->rccl.CommAbort(nd->comm[p]);
         nd->comm[p] = NULL;
       }
+      pthread_mutex_unlock(&nd->comm_m[p]);
     }
   }
   pthread_mutex_unlock(&sync->abort_m);
@@ -426,7 +449,11 @@ static void *shard_gather(void *arg)
       /* the chunk leaves by ncclSend behind its kernel; the root's thread posts the matching receive */
       e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
       if (e == hipSuccess) {
-        const int ne = nd->rccl.Send(P->d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
+        pthread_mutex_lock(&nd->comm_m[s]);
+        const bool gone = nd->comm[s] == NULL; /* another shard failed and aborted the exchange: stop, no error of ours */
+        const int ne = gone ? 0 : nd->rccl.Send(P->d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
+        pthread_mutex_unlock(&nd->comm_m[s]);
+        if (gone) break;
         if (ne != 0) {
           nd->last_rccl_error = ne;
           j->rc = VS_ERR_HIP;
@@ -461,6 +488,11 @@ static void *shard_gather(void *arg)
      * one stream, straight into the peer's rows of the root buffer */
     const size_t rounds = vs_gather_rounds(j->n_total, S, VS_NODE_CHUNK);
     for (size_t kk = 0; kk < rounds && j->rc == VS_OK && !atomic_load(&sync->aborted); kk++) {
+      pthread_mutex_lock(&nd->comm_m[0]);
+      if (nd->comm[0] == NULL) { /* aborted by a failing shard between two rounds */
+        pthread_mutex_unlock(&nd->comm_m[0]);
+        break;
+      }
       int ne = nd->rccl.GroupStart();
       for (int p = 1; p < S && ne == 0; p++) {
         size_t r0 = 0, rows = 0;
@@ -469,6 +501,7 @@ static void *shard_gather(void *arg)
                            nd->comm[0], nd->recv);
       }
       const int ge = nd->rccl.GroupEnd();
+      pthread_mutex_unlock(&nd->comm_m[0]);
       if (ne == 0) ne = ge;
       if (ne != 0) {
         nd->last_rccl_error = ne;
@@ -550,8 +583,9 @@ int vs_node_synth_gather(vs_node *nd, const vs_lane *lanes, size_t n_lanes, size
   }
   if (max_compute_ms) *max_compute_ms = mc;
   if (atomic_load(&sync.aborted) && nd->transport == VS_NODE_TRANSPORT_RCCL) {
-    /* the communicators were aborted: the node is back on the peer transport (vs_node_set_transport makes new ones) */
-    vs_node_drop_rccl(nd);
+    /* the communicators were aborted: the node is back on the peer transport (vs_node_set_transport makes new
+     * ones); librccl itself stays loaded until the node is destroyed */
+    vs_node_drop_rccl(nd, true);
     nd->transport = VS_NODE_TRANSPORT_PEER;
     memcpy(nd->link, nd->base_link, sizeof(nd->link));
   }
