@@ -410,6 +410,10 @@ def main():
     plan = eng.plan(lanes, n_samples)                     # lane records + cos rows -> HBM
     plan_host_ms, plan_upload_ms = plan.timing()
     kernel_name = plan.kernel_name(vs.VS_KIND_SYNTH)
+    # the three-role layouts are built on "wavefront w of a workgroup runs on SIMD w % 4": asked of the hardware
+    # (HW_ID probe), and the plan says whether it had to fall back to two roles
+    c12, c8 = eng.simd_dealing()
+    wave_to_simd = dict(plan.roles(), cyclic_12_wavefronts=c12, cyclic_8_wavefronts=c8)
     out = torch.empty((per_gpu, pitch), dtype=torch.int16, device=dev)
 
     def launch():
@@ -606,6 +610,7 @@ def main():
                      "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
                              "sort, cos rows; allocation + upload + wait.  Outside every timed region."},
             "launch_health_word": health,
+            "wave_to_simd": wave_to_simd,
             "device": dev_name.strip(),
             "ranks_seen": ranks_seen,
             "distinct_devices": distinct_devices,

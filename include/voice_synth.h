@@ -200,6 +200,7 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
 #define VS_FAULT_SHORT_COS_ROWS 2    /* tests: the kernel finds no room for its cos rows (plan and kernel disagree) */
 #define VS_FAULT_SHARD_PREPARE 3     /* tests: a context that serves a shard of a node fails to prepare its chunks (vs_node_synth_gather) */
 #define VS_FAULT_SHARD_HANDOVER 4    /* tests: ... fails while handing its first chunk over, after the others have started */
+#define VS_FAULT_SIMD_DEALING 5      /* tests: plans behave as if vs_ctx_simd_dealing() had found the wavefronts NOT dealt four at a time */
 typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
   int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */
@@ -217,10 +218,20 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
 /* Device self-test of the arithmetic shortcuts the kernels take: [0] division shortcut
  * (exhaustive over all 2^31 draws), [1] Philox known answers, [2] integer square root,
  * [3] rounding, [4] one-fma noise sample (exhaustive over the draws at 16 widths), [5] two-block
- * Philox with prepared round keys.  failures (optional) receives VS_SELFTEST_COUNTERS
- * counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
-#define VS_SELFTEST_COUNTERS 6
+ * Philox with prepared round keys, [6] workgroups of the wave-to-SIMD probe below that were NOT dealt
+ * "wavefront w next to wavefront w % 4" (a performance assumption, not a correctness one -- but on the hardware this
+ * library is written for it holds, and a chip where it does not is worth a failed self-test).  failures
+ * (optional) receives VS_SELFTEST_COUNTERS counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
+#define VS_SELFTEST_COUNTERS 7
 int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures);
+/* How the hardware deals the wavefronts of a workgroup to the four SIMDs of a compute unit, read from HW_ID by a
+ * one-workgroup-per-CU probe launch (once per context, cached): *cyclic12 / *cyclic8 = 1 if in every probed
+ * 12- / 8-wavefront workgroup the first four wavefronts ran on four different SIMDs and wavefront w ran on the SIMD
+ * of wavefront w % 4 (MI355X: four rotations of the order 0, 2, 1, 3) -- what the three-role layouts of the fused
+ * kernel are built on (the three wavefronts of ONE group share a SIMD; on half-filled chips the filter wavefront has one to
+ * itself).  Where it does not hold, plans take the two-role kernel instead of running the three roles in an order
+ * that is 2.5 x slower (vs_plan_roles says so). */
+int vs_ctx_simd_dealing(vs_ctx *ctx, int *cyclic12, int *cyclic8);
 /* Name, CU count of the device in use. */
 int vs_ctx_device_info(const vs_ctx *ctx, char *name, size_t name_len, int *cu_count);
 /* PCI bus id of the device in use ("0000:05:00.0", hipDeviceGetPCIBusId): what tells two devices of a node
@@ -271,6 +282,10 @@ int vs_plan_timing(const vs_plan *plan, double *host_ms, double *upload_ms);
 int vs_plan_kernel_name(const vs_plan *plan, int kind, char *buf, size_t len);
 
 /* Dynamic LDS bytes per 64-lane workgroup and launch geometry a plan will use. */
+/* Launch shape of the fused kind: *roles = wavefronts per 64 utterances (1 = the one-wave kernel, 2, 3), *layout =
+ * 0 role-major / 1 spread (the filter wavefront alone on its SIMD), *simd_fallback = 1 if the plan wanted three
+ * roles and took two because vs_ctx_simd_dealing() found the wavefronts dealt differently.  Any pointer may be NULL. */
+int vs_plan_roles(const vs_plan *plan, int *roles, int *layout, int *simd_fallback);
 int vs_plan_info(const vs_plan *plan, size_t *lds_bytes, size_t *n_workgroups,
                  size_t *ring_slots);
 

@@ -158,7 +158,38 @@ def test_device_selftest(engine):
     """exhaustive on the device: the 3-instruction division shortcut equals IEEE division for
     all 2^31 draws; Philox known answer; integer square root; round2int against the literal form"""
     rc, fails = engine.selftest()
-    assert rc == 0 and fails == [0, 0, 0, 0, 0, 0], fails
+    assert rc == 0 and fails == [0, 0, 0, 0, 0, 0, 0], fails
+
+
+def test_wavefronts_are_dealt_to_the_simds_cyclically_and_plans_fall_back_when_not():
+    """what the three-role layouts are built on: wavefront w of a workgroup runs on SIMD w % 4 -- read
+    from HW_ID by a probe launch (vs_ctx_simd_dealing), for 12- and for 8-wavefront workgroups, on MI355X.  A plan on a
+    device where it does not hold (provoked through vs_tuning.fault) takes two roles instead of three in the wrong order,
+    says so (vs_plan_roles) -- and still synthesises the same samples."""
+    eng = vs.Engine(0)
+    try:
+        assert eng.simd_dealing() == (True, True)
+        for index, n, shape in ((3, 65536, ("role-major", "vs_synth_ws_kernel<0, true, 3>")), (4, 32768, ("spread", "vs_synth_ws_kernel<0, true, 3>"))):
+            lanes, ns = _lanes(index, n)
+            eng.set_tuning()
+            plan = eng.plan(lanes, ns)
+            assert plan.roles() == {"roles": 3, "layout": shape[0], "simd_fallback": False}
+            assert plan.kernel_name() == shape[1]
+            plan.close()
+            eng.set_tuning(fault=vs.VS_FAULT_SIMD_DEALING)
+            plan = eng.plan(lanes, ns)
+            assert plan.roles() == {"roles": 2, "layout": "role-major", "simd_fallback": True}
+            assert plan.kernel_name() == "vs_synth_ws_kernel<0, true, 2>"
+            plan.close()
+        # the fallback's samples are the oracle's
+        lanes, ns = _lanes(3, 65536)
+        sub = (vs.Lane * 192).from_buffer(lanes)
+        eng.set_tuning(fault=vs.VS_FAULT_SIMD_DEALING, kernel=vs.VS_KERNEL_WS, ws_pairs=4)
+        got = eng.synth(sub, ns)
+        assert np.array_equal(got, po.synth(sub, ns))
+    finally:
+        eng.set_tuning()
+        eng.close()
 
 
 @pytest.mark.parametrize("index,n", [(2, 64), (3, 130), (4, 40), (5, 100)])

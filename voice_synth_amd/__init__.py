@@ -32,6 +32,7 @@ from ._ffi import (  # noqa: F401
     VS_FAULT_SHORT_COS_ROWS,
     VS_FAULT_SHARD_PREPARE,
     VS_FAULT_SHARD_HANDOVER,
+    VS_FAULT_SIMD_DEALING,
     check,
     load,
 )
@@ -189,10 +190,16 @@ class Engine:
         check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
 
     def selftest(self):
-        """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2] failure counts)"""
-        f = (C.c_uint64 * 6)()
+        """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2, wave-to-SIMD dealing] failure counts)"""
+        f = (C.c_uint64 * 7)()
         rc = self._lib.vs_ctx_selftest(self._ctx, f)
         return rc, [int(v) for v in f]
+
+    def simd_dealing(self):
+        """vs_ctx_simd_dealing(): (wavefront w of a 12-wavefront workgroup ran on SIMD w % 4, ... of an 8-wavefront one)"""
+        a, b = C.c_int(), C.c_int()
+        check(self._lib.vs_ctx_simd_dealing(self._ctx, C.byref(a), C.byref(b)), "vs_ctx_simd_dealing")
+        return bool(a.value), bool(b.value)
 
     def device_info(self):
         name = C.create_string_buffer(128)
@@ -404,6 +411,13 @@ class Plan:
         buf = C.create_string_buffer(128)
         check(self._lib.vs_plan_kernel_name(self._plan, int(kind), buf, 128), "vs_plan_kernel_name")
         return buf.value.decode()
+
+    def roles(self):
+        """vs_plan_roles(): wavefronts per 64 utterances of the fused kind (1 = the one-wave kernel), the layout, and whether
+        the plan fell back from three roles to two because the wavefronts are not dealt w % 4"""
+        r, l, f = C.c_int(), C.c_int(), C.c_int()
+        check(self._lib.vs_plan_roles(self._plan, C.byref(r), C.byref(l), C.byref(f)), "vs_plan_roles")
+        return {"roles": r.value, "layout": "spread" if l.value else "role-major", "simd_fallback": bool(f.value)}
 
     def info(self):
         lds, wgs, slots = C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -149,6 +149,7 @@ VS_FAULT_WITHHOLD_PROGRESS = 1
 VS_FAULT_SHORT_COS_ROWS = 2
 VS_FAULT_SHARD_PREPARE = 3
 VS_FAULT_SHARD_HANDOVER = 4
+VS_FAULT_SIMD_DEALING = 5
 VS_DF_FAST = 0x8
 
 
@@ -177,6 +178,8 @@ SYMBOLS = {
     "vs_ctx_last_hip_error": (C.c_int, [_vp]),
     "vs_ctx_set_tuning": (C.c_int, [_vp, _P(Tuning)]),
     "vs_ctx_selftest": (C.c_int, [_vp, _P(C.c_uint64)]),
+    "vs_ctx_simd_dealing": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int)]),
+    "vs_plan_roles": (C.c_int, [_vp, _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     "vs_ctx_device_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, _P(C.c_int)]),
     "vs_ctx_device_pci": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "vs_plan_create": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _P(_vp)]),

@@ -111,7 +111,7 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->gen_low != 0 && t->gen_low < VS_SS) return VS_ERR_ARG;
   if (t->gen_min < 0 || t->gen_min > 64) return VS_ERR_ARG;
   if (t->spin_limit < 0) return VS_ERR_ARG;
-  if (t->fault < 0 || t->fault > VS_FAULT_SHARD_HANDOVER) return VS_ERR_ARG;
+  if (t->fault < 0 || t->fault > VS_FAULT_SIMD_DEALING) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
   ctx->tuning = *t;
@@ -166,6 +166,70 @@ int vs_ctx_synchronize(vs_ctx *ctx)
   return VS_OK;
 }
 
+/* One probe launch per workgroup size: a workgroup per CU (most of the LDS each, like the fused launches), every
+ * wavefront reports its HW_ID; "cyclic" = in every workgroup the first four wavefronts run on four different SIMDs
+ * and wavefront w runs where wavefront w % 4 does. */
+static int simd_probe(vs_ctx *ctx)
+{
+  if (ctx->simd_probed) return ctx->simd_probed > 0 ? VS_OK : VS_ERR_HIP;
+  const unsigned grid = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
+  unsigned *d = NULL, *h = (unsigned *)calloc((size_t)grid * 16, sizeof(unsigned));
+  ctx->simd_probed = -1;
+  ctx->simd_cyclic12 = ctx->simd_cyclic8 = 0;
+  ctx->simd_odd_wgs = 0;
+  if (!h) return VS_ERR_NOMEM;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&d, (size_t)grid * 16 * sizeof(unsigned));
+  int ok[2] = {1, 1};
+  unsigned odd = 0;
+  for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
+    const int waves = pass == 0 ? 12 : 8;
+    memset(h, 0, (size_t)grid * 16 * sizeof(unsigned));
+    e = hipMemcpyAsync(d, h, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = vs_launch_simd_probe(waves, grid, (size_t)VS_LDS_LIMIT - 8192, d, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) break;
+    for (unsigned g = 0; g < grid; g++) {
+      /* "dealt four at a time": the first four wavefronts land on four DIFFERENT SIMDs (in whatever order -- MI355X
+       * shows four rotations of (0, 2, 1, 3)) and wavefront w joins wavefront w % 4, on the same CU */
+      int good = 1;
+      unsigned seen = 0;
+      for (int w = 0; w < waves; w++) {
+        const unsigned hw = h[(size_t)g * 16 + (size_t)w], first = h[(size_t)g * 16 + (size_t)(w & 3)];
+        if (!(hw & 0x80000000u)) good = 0;
+        if (w < 4) seen |= 1u << ((hw >> 4) & 3u);
+        else if (((hw >> 4) & 3u) != ((first >> 4) & 3u) || ((hw >> 8) & 0xFFu) != ((first >> 8) & 0xFFu)) good = 0;
+      }
+      if (seen != 0xFu) good = 0;
+      if (!good) {
+        ok[pass] = 0;
+        odd++;
+      }
+    }
+  }
+  if (d) (void)hipFree(d);
+  free(h);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    return VS_ERR_HIP;
+  }
+  ctx->simd_cyclic12 = ok[0];
+  ctx->simd_cyclic8 = ok[1];
+  ctx->simd_odd_wgs = odd;
+  ctx->simd_probed = 1;
+  return VS_OK;
+}
+
+int vs_ctx_simd_dealing(vs_ctx *ctx, int *cyclic12, int *cyclic8)
+{
+  if (!ctx) return VS_ERR_ARG;
+  const int rc = simd_probe(ctx);
+  if (cyclic12) *cyclic12 = ctx->simd_cyclic12;
+  if (cyclic8) *cyclic8 = ctx->simd_cyclic8;
+  return rc;
+}
+
 int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
 {
   if (!ctx) return VS_ERR_ARG;
@@ -181,6 +245,8 @@ int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures)
     ctx->last_hip_error = (int)e;
     return VS_ERR_HIP;
   }
+  /* [6]: workgroups of the wave-to-SIMD probe that were not dealt four at a time (all of them if the probe failed) */
+  h[6] = (simd_probe(ctx) == VS_OK) ? ctx->simd_odd_wgs : 1ull;
   unsigned long long any = 0;
   for (int k = 0; k < VS_SELFTEST_COUNTERS; k++) {
     if (failures) failures[k] = h[k];
@@ -374,7 +440,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (tune->ring_slots > 0) cap = tune->ring_slots;
   int slots = 0, ready_min = 32;
   size_t lds_bytes = 0;
-  int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2, ws_layout = VS_WS_LAYOUT_ROLE_MAJOR;
+  int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2, ws_layout = VS_WS_LAYOUT_ROLE_MAJOR, simd_fallback = 0;
   bool all_deep = true; /* every group's ring holds 1.65 of its longest cycles or more (see the thresholds below) */
   if (!filter_only) {
     /* Half-filled chips (at most two groups per CU) have LDS to spare: rings of 2.4 of the longest cycle instead of
@@ -447,6 +513,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
         ws_roles = 3;
       if (tune->ws_roles == 2) ws_roles = 2;
       if (tune->ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+      /* Both three-role layouts are built on "wavefront w runs on the SIMD of wavefront w % 4": role-major puts the three wavefronts
+       * of ONE group on one SIMD (12 wavefronts), the spread layout keeps the filter wavefront alone (8).  Asked of
+       * the hardware once per context (a probe launch, vs_ctx_simd_dealing); where it does not hold, two roles --
+       * slower than three done right, much faster than three in the wrong order (6.4 against 2.6 ms). */
+      if (ws_roles == 3 && ws_pairs > 1) {
+        const bool dealt = tune->fault != VS_FAULT_SIMD_DEALING && simd_probe(ctx) == VS_OK &&
+                           (ws_pairs == 4 ? ctx->simd_cyclic12 : ctx->simd_cyclic8);
+        if (!dealt) {
+          ws_roles = 2;
+          simd_fallback = 1;
+        }
+      }
       if (ws_roles == 3) ws_pair_bytes = bytes3;
       if (ws_roles == 3 && ws_pairs == 2) ws_layout = VS_WS_LAYOUT_SPREAD_2X3;
     }
@@ -470,6 +548,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
   p->ws_layout = ws_layout;
+  p->simd_fallback = simd_fallback;
   p->ws_shared_simd = (wave_specialised && grid > 2u * cus) ? 1 : 0;
   p->group_lanes = group_lanes;
   p->ws_pair_bytes = ws_pair_bytes;
@@ -603,6 +682,15 @@ int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
   else
     snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
              pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");
+  return VS_OK;
+}
+
+int vs_plan_roles(const vs_plan *p, int *roles, int *layout, int *simd_fallback)
+{
+  if (!p) return VS_ERR_ARG;
+  if (roles) *roles = p->wave_specialised ? p->ws_roles : 1;
+  if (layout) *layout = p->wave_specialised ? p->ws_layout : 0;
+  if (simd_fallback) *simd_fallback = p->simd_fallback;
   return VS_OK;
 }
 

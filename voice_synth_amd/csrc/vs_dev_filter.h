@@ -25,7 +25,7 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
  * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
  * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
  */
-template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1>
+template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1, bool LATE = false>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
@@ -66,9 +66,25 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
    * result instead of eight integers -- the three registers between 168 and a spill of the three-role kernel's
    * pre-emphasis variants */
   constexpr bool EAGER = PACKED && (WHOLE == 1);
-  uint32_t pk[4];
+  /* LATE (the two-role kernels, which run at two wavefronts per SIMD and have the registers): the packed words of the
+   * whole super-step are held -- 12 registers instead of 4 -- and leave as three 16-byte stores back to back at its
+   * end.  Measured, same box (profiles/r05_store_width_probe.txt): config 2 -4 %, config 5 -1.5 % exact, fma alike;
+   * HBM write traffic 1.11 x instead of 1.08 x the algorithmic bytes (the L2 merges early stores better, as round 3
+   * found on the three-role kernel) -- taken for the time, not for the traffic. */
+  constexpr int PKN = (EAGER && LATE) ? 12 : 4;
+  uint32_t pk[PKN];
   auto put8 = [&](int k) {
-    if (EAGER) {
+    if (EAGER && LATE) {
+      if (k == VS_SS / 8 - 1) {
+#pragma unroll
+        for (int c = 0; c < VS_SS / 8; ++c) {
+          vs_u32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = pk[(4 * c + e) % PKN];
+          if (store_ok) *(vs_u32x4 *)(orow + n + 8 * c) = v;
+        }
+      }
+    } else if (EAGER) {
       vs_u32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = pk[e];
@@ -157,7 +173,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
         qlo = (olo > qlo) ? olo : qlo;
       }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
-      if (EAGER && (t & 1)) pk[(t & 7) >> 1] = vs_clamp_pack16(outv[t - 1], outv[t]);
+      if (EAGER && (t & 1)) pk[(t >> 1) % PKN] = vs_clamp_pack16(outv[t - 1], outv[t]);
       if ((t & 7) == 7) put8(t >> 3);
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
@@ -178,7 +194,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       for (int k = 0; k < VS_SS / 8; ++k) {
         if (EAGER) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) pk[e] = vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
+          for (int e = 0; e < 4; ++e) pk[(4 * k + e) % PKN] = vs_clamp_pack16(outv[8 * k + 2 * e], outv[8 * k + 2 * e + 1]);
         }
         put8(k);
       }

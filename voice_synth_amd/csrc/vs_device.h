@@ -91,7 +91,9 @@ typedef struct VsKernelArgs {
   int ws_layout;       /* wave-specialised kernels, how a workgroup's wavefronts map to roles: VS_WS_LAYOUT_* */
 } VsKernelArgs;
 
-/* Wavefronts of a workgroup are dealt to the CU's four SIMDs cyclically (wavefront w runs on SIMD w % 4).
+/* Wavefronts of a workgroup are dealt to the CU's four SIMDs four at a time: wavefront w runs on the SIMD of wavefront
+ * w % 4, and the first four on four different SIMDs (on MI355X a rotation of 0, 2, 1, 3 -- read from HW_ID by
+ * vs_ctx_simd_dealing, which every plan that picks one of these layouts consults; "SIMD k" below = the SIMD of wavefront k).
  *   ROLE_MAJOR  role = w / groups, group = w % groups: with four groups per workgroup the two or three wavefronts
  *               of ONE group share a SIMD (full grids); with one or two groups every wavefront has a SIMD of its own.
  *   SPREAD_2X3  two groups x three roles in EIGHT wavefronts, F0 O0 F1 O1 -- N0 -- N1 (two of them leave at once):

@@ -48,6 +48,12 @@ struct vs_ctx {
   int cu_count;
   vs_tuning tuning; /* all zero = the library's own choices */
   VsPool pool;
+  /* where the hardware deals the wavefronts of a workgroup (vs_ctx_simd_dealing): asked once, the first time a
+   * plan wants a layout that is built on it */
+  int simd_probed;        /* 0: not yet; 1: done; -1: the probe itself failed (treated as "not cyclic") */
+  int simd_cyclic12;      /* wavefront w of a 12-wavefront workgroup ran next to wavefront w % 4 (first four on different SIMDs) in every workgroup probed */
+  int simd_cyclic8;       /* ... of an 8-wavefront workgroup */
+  unsigned simd_odd_wgs;  /* workgroups of the probe that were dealt differently (selftest counter [6]) */
 };
 
 struct vs_plan {
@@ -69,6 +75,7 @@ struct vs_plan {
   int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
   int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */
   int ws_layout;     /* VS_WS_LAYOUT_* (VsKernelArgs.ws_layout) */
+  int simd_fallback; /* the plan wanted three roles and took two because the wavefronts are not dealt four at a time */
   int ws_shared_simd; /* the wavefronts of a group share a SIMD (grids beyond two groups per CU) */
   int group_lanes;   /* utterances per wavefront: VS_WAVE, or VS_NARROW_LANES for periods beyond the 64-column ring */
   int ws_pair_bytes; /* LDS bytes of one pair */
@@ -98,6 +105,7 @@ struct vs_plan {
 extern "C" {
 #endif
 hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
+hipError_t vs_launch_simd_probe(int waves, unsigned grid, size_t lds_bytes, unsigned *out_dev, hipStream_t stream);
 hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
 hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream);
 hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1, const VsKernelArgs *args,

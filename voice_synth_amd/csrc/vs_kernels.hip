@@ -569,8 +569,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
       await(n);
       int outv[VS_SS];
       vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                        N, true, outv, xpre, true);
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                                 N, true, outv, xpre, true);
       release(n + VS_SS);
       VS_DIAG_ADD(dg, 0)
     }
@@ -613,8 +613,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
           if (ready) {
             int outv[VS_SS];
             vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
-                                                              n, N, true, outv, xpre);
+            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                                       n, N, true, outv, xpre);
           }
         } else {
           if (ready) {
@@ -1045,6 +1045,36 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     if (o0 == p0 && o1 == p1) b1++;
     if (b1) atomicAdd(&bad[1], b1);
   }
+}
+
+/*
+ * Where the hardware puts the wavefronts of a workgroup (vs_ctx_simd_dealing): every wavefront of a workgroup of
+ * `blockDim.x / 64` wavefronts that has a CU to itself (the launcher asks for most of the LDS, as the fused launches
+ * do) writes its HW_ID register.  The wave-specialised layouts are built on wavefront w running on the SIMD of wavefront w % 4
+ * (vs_device.h): correctness does not depend on it, the launch time does (role-major against the wrong order:
+ * 2.6 against 6.4 ms, profiles/r04_config4_roles.txt) -- so the plan asks instead of assuming.
+ * HW_ID (gfx9 family): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13].
+ */
+__global__ void __launch_bounds__(1024) vs_simd_probe_kernel(unsigned *out)
+{
+  extern __shared__ __attribute__((aligned(16))) int16_t probe_lds[];
+  if ((threadIdx.x & (VS_WAVE - 1)) == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); /* hwreg(HW_REG_HW_ID, 0, 32) */
+    out[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = hw | 0x80000000u;     /* bit 31: "written" */
+    if (threadIdx.x == 0) probe_lds[0] = (int16_t)hw;                         /* the LDS is really allocated */
+  }
+  __syncthreads(); /* every wavefront of the workgroup is resident at the same time */
+}
+
+extern "C" hipError_t vs_launch_simd_probe(int waves, unsigned grid, size_t lds_bytes, unsigned *out_dev, hipStream_t stream)
+{
+  if (waves < 1 || waves > 16) return hipErrorInvalidValue;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)vs_simd_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(vs_simd_probe_kernel, dim3(grid), dim3((unsigned)waves * VS_WAVE), lds_bytes, stream, out_dev);
+  return hipGetLastError();
 }
 
 extern "C" hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream)
