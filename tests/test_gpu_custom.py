@@ -231,3 +231,39 @@ def test_filter_only_accepts_any_sample_rate(engine):
     flow = rng.integers(-12000, 12000, size=(64, 20000), dtype=np.int16)
     got = engine.filter(lanes, flow)
     assert np.array_equal(got, po.filter(lanes, flow))
+
+
+def test_small_host_calls_run_without_a_single_copy():
+    """vs_source / vs_filter of a handful of utterances -- what the two drop-in programs call -- on a context that has
+    not copied anything yet: the plan's records, the flow, the PCM, the cycle log and the counts live in pinned,
+    device-mapped host memory (VS_PLAN_ZERO_COPY; a process that only does this never pays the runtime's 27 ms
+    copy-path set-up).  Same samples, same log as the oracle; a device-side check that fails still reaches the caller
+    (the error word is host memory the kernel writes with an atomic over PCIe)."""
+    specs, fs, dur, _ = configs.config_specs(3, 5)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    eng = vs.Engine(0)                      # fresh context: nothing has been copied on it
+    try:
+        flow, recs, ncyc = eng.source(lanes, ns, log_cycles=160)
+        want_flow = po.source(lanes, ns)
+        assert np.array_equal(flow, want_flow)
+        for l in range(5):
+            _, want_recs, want_ncyc, _ = po.source_one(lanes[l], ns, max_recs=160)
+            assert ncyc[l] == want_ncyc
+            for field in ("T", "S", "x_pow", "w_pow"):
+                assert np.array_equal(recs[l, :ncyc[l]][field], want_recs[field])
+            assert not recs[l, ncyc[l]:]["T"].any()      # rows behind the last cycle were zeroed (by the CPU here)
+        pcm = eng.filter(lanes, flow)
+        assert np.array_equal(pcm, po.synth(lanes, ns))
+        assert np.array_equal(eng.source(lanes, ns), want_flow)       # the pooled block is reused
+        eng.set_tuning(fault=vs.VS_FAULT_SHORT_COS_ROWS)
+        with pytest.raises(vs.VsError) as e:
+            eng.source(lanes, ns)
+        assert e.value.code == _ffi.VS_ERR_INTERNAL
+        eng.set_tuning()
+        # ... and once the context has made a plan that copies, small calls take the copy path: same answer
+        big, _ = vs.lanes_from_specs(configs.config_specs(3, 200)[0])
+        assert np.array_equal(eng.synth(big, 2000)[:5], po.synth(big, 2000)[:5])
+        assert np.array_equal(eng.source(lanes, ns), want_flow)
+    finally:
+        eng.close()

@@ -46,28 +46,6 @@ int vs_ctx_create(int device, vs_ctx **out)
   ctx->cu_count = prop.multiProcessorCount;
   memset(&ctx->tuning, 0, sizeof(ctx->tuning));
   memset(&ctx->pool, 0, sizeof(ctx->pool));
-  /* The HIP runtime sets up its copy path (staging buffers, the transfer queue of this device) at a
-   * process's first host-to-device copy: 8 ms on a bare process, ~100 ms in one that has loaded PyTorch
-   * (profiles/r04_plan_cost.txt).  Paid HERE, once per context, so that the first vs_plan_create of a
-   * process costs what every later one costs. */
-  {
-    void *scratch = NULL;
-    const size_t warm_bytes = 1u << 20;
-    void *host = malloc(warm_bytes);
-    hipError_t e = host ? hipMalloc(&scratch, warm_bytes) : hipErrorOutOfMemory;
-    if (e == hipSuccess) {
-      memset(host, 0, warm_bytes);
-      e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, NULL);
-      if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, NULL);
-      if (e == hipSuccess) e = hipStreamSynchronize(NULL);
-      (void)hipFree(scratch);
-    }
-    free(host);
-    if (e != hipSuccess) {
-      free(ctx);
-      return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
-    }
-  }
   /* Experiments only (tools/gpu_sweep.sh): with VS_DEBUG_TUNING=1 in the environment the knobs
    * are read ONCE, here, and go through the same validation as vs_ctx_set_tuning().  Without it
    * no environment variable can change what the library launches. */
@@ -92,6 +70,37 @@ int vs_ctx_create(int device, vs_ctx **out)
     }
   }
   *out = ctx;
+  return VS_OK;
+}
+
+/* The HIP runtime sets up its copy path (staging buffers, the transfer queue of this device) at a process's first
+ * host-to-device copy: 27 ms on a bare process whatever the size (tools/hip_startup_probe.c), ~100 ms in one that
+ * has loaded PyTorch (profiles/r04_plan_cost.txt).  Paid HERE, once per context, the first time a plan that copies
+ * is made and before that plan's clock starts -- so that a first vs_plan_create costs what every later one costs --
+ * and NOT by vs_ctx_create: the drop-in programs make zero-copy plans only (VS_PLAN_ZERO_COPY) and never copy. */
+int vs_copy_path_warm(vs_ctx *ctx)
+{
+  if (ctx->copy_warm) return VS_OK;
+  const double t0 = vs_now_ms();
+  void *scratch = NULL;
+  const size_t warm_bytes = 1u << 20;
+  void *host = malloc(warm_bytes);
+  hipError_t e = host ? hipSetDevice(ctx->device) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipMalloc(&scratch, warm_bytes);
+  if (e == hipSuccess) {
+    memset(host, 0, warm_bytes);
+    e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, NULL);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, NULL);
+    if (e == hipSuccess) e = hipStreamSynchronize(NULL);
+    (void)hipFree(scratch);
+  }
+  free(host);
+  if (e != hipSuccess) {
+    ctx->last_hip_error = (int)e;
+    return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
+  }
+  ctx->copy_warm = 1;
+  ctx->copy_warm_ms = vs_now_ms() - t0;
   return VS_OK;
 }
 
@@ -290,9 +299,14 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
                         int mode, vs_plan **out)
 {
   const int filter_only = (mode & VS_PLAN_FILTER_ONLY) ? 1 : 0;
+  const int zero_copy = (mode & VS_PLAN_ZERO_COPY) ? 1 : 0;
   if (!ctx || !lanes || !out || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
   if (n_lanes > (size_t)0x7FFFFFC0 || n_samples > (size_t)0x7FFFFF00) return VS_ERR_UNSUPPORTED;
   *out = NULL;
+  if (!zero_copy) {
+    const int wrc = vs_copy_path_warm(ctx);
+    if (wrc != VS_OK) return wrc;
+  }
   const vs_tuning *tune = &ctx->tuning;
   int rc = VS_OK;
   /* host memory of this call, released at `done` */
@@ -560,13 +574,36 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
 
   const double t_host1 = vs_now_ms();
   hipError_t e = hipSetDevice(ctx->device);
-  if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
-  if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab_len + 1) * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+  const size_t zc_lanes = n_lanes * sizeof(VsDevLane), zc_cos = (costab_len + 1) * sizeof(double);
+  const size_t zc_off_cos = (zc_lanes + 63) & ~(size_t)63, zc_off_err = (zc_off_cos + zc_cos + 63) & ~(size_t)63;
+  const size_t zc_off_wide = zc_off_err + 64, zc_wide = wide ? n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double) : 0;
+  if (zero_copy) {
+    /* one pinned, device-mapped host block: the CPU writes the records, the kernel reads them over PCIe (a few
+     * hundred bytes per utterance, once), the error word is read back by the CPU -- no copy engine involved */
+    void *dev = NULL;
+    if (e == hipSuccess) e = hipHostMalloc(&p->zc_host, zc_off_wide + zc_wide + 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dev, p->zc_host, 0);
+    if (e == hipSuccess) {
+      char *hb = (char *)p->zc_host, *db = (char *)dev;
+      memcpy(hb, dl, zc_lanes);
+      if (costab_len) memcpy(hb + zc_off_cos, costab, costab_len * sizeof(double));
+      p->zc_err = (int *)(hb + zc_off_err);
+      *p->zc_err = 0;
+      if (wide) memcpy(hb + zc_off_wide, awide, zc_wide);
+      p->d_lanes = (VsDevLane *)db;
+      p->d_costab = (double *)(db + zc_off_cos);
+      p->d_err = (int *)(db + zc_off_err);
+      if (wide) p->d_awide = (double *)(db + zc_off_wide);
+    }
+  } else {
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab_len + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+    if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
+  }
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
-  if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
   if (e == hipSuccess && wide && !filter_only) {
     const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
     if (mode & VS_PLAN_POOL_SCRATCH) {
@@ -583,25 +620,20 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
    * that the wait below is for THESE copies and not for the previous chunk's kernel; the launch that
    * uses them is enqueued after this function has returned */
   hipStream_t up = ctx->upload ? ctx->upload : ctx->stream;
-  if (e == hipSuccess && wide)
-    e = hipMemcpyAsync(p->d_awide, awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double), hipMemcpyHostToDevice, up);
-  static const int zero_word = 0; /* a copy, not hipMemsetAsync: a process's first memset loads the runtime's fill kernel (20 ms) */
-  if (e == hipSuccess) e = hipMemcpyAsync(p->d_err, &zero_word, sizeof(int), hipMemcpyHostToDevice, up);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(p->d_lanes, dl, n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
-  if (e == hipSuccess && costab_len)
-    e = hipMemcpyAsync(p->d_costab, costab, costab_len * sizeof(double), hipMemcpyHostToDevice, up);
-  if (e == hipSuccess) e = hipStreamSynchronize(up);
+  if (!zero_copy) {
+    if (e == hipSuccess && wide)
+      e = hipMemcpyAsync(p->d_awide, awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double), hipMemcpyHostToDevice, up);
+    static const int zero_word = 0; /* a copy, not hipMemsetAsync: a process's first memset loads the runtime's fill kernel (20 ms) */
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_err, &zero_word, sizeof(int), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(p->d_lanes, dl, n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess && costab_len)
+      e = hipMemcpyAsync(p->d_costab, costab, costab_len * sizeof(double), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess) e = hipStreamSynchronize(up);
+  }
   if (e != hipSuccess) {
     ctx->last_hip_error = (int)e;
-    if (p->d_lanes) (void)hipFree(p->d_lanes);
-    if (p->d_costab) (void)hipFree(p->d_costab);
-    if (p->d_err) (void)hipFree(p->d_err);
-    if (p->d_sink) (void)hipFree(p->d_sink);
-    if (p->d_opow) (void)hipFree(p->d_opow);
-    if (p->d_awide) (void)hipFree(p->d_awide);
-    if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
-    free(p);
+    vs_plan_destroy(p); /* frees whatever was allocated */
     p = NULL;
     rc = VS_ERR_HIP;
     goto done;
@@ -629,12 +661,16 @@ void vs_plan_destroy(vs_plan *p)
 {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
-  if (p->d_lanes) (void)hipFree(p->d_lanes);
-  if (p->d_costab) (void)hipFree(p->d_costab);
-  if (p->d_err) (void)hipFree(p->d_err);
+  if (p->zc_host) {
+    (void)hipHostFree(p->zc_host); /* records, cos rows, error word and wide taps of a zero-copy plan */
+  } else {
+    if (p->d_lanes) (void)hipFree(p->d_lanes);
+    if (p->d_costab) (void)hipFree(p->d_costab);
+    if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_awide) (void)hipFree(p->d_awide);
+  }
   if (p->d_sink) (void)hipFree(p->d_sink);
   if (p->d_opow) (void)hipFree(p->d_opow);
-  if (p->d_awide) (void)hipFree(p->d_awide);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   free(p);
 }
@@ -645,8 +681,13 @@ int vs_plan_status(vs_plan *p, int *flags)
   vs_ctx *ctx = p->ctx;
   int word = 0;
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_HIP(ctx, hipMemcpyAsync(&word, p->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (p->zc_err) { /* zero-copy plan: the word lives in host memory the device writes through PCIe */
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    word = *(volatile int *)p->zc_err;
+  } else {
+    VS_HIP(ctx, hipMemcpyAsync(&word, p->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (flags) *flags = word;
   return word ? VS_ERR_INTERNAL : VS_OK;
 }

@@ -94,6 +94,7 @@ void vs_pool_release(vs_ctx *ctx)
   if (P->d_in) (void)hipFree(P->d_in);
   if (P->d_aux) (void)hipFree(P->d_aux);
   if (P->d_flow) (void)hipFree(P->d_flow);
+  if (P->zc_io) (void)hipHostFree(P->zc_io);
   for (int t = 0; t < VS_DELIVERY_THREADS; t++) {
     if (P->staging[t]) (void)hipHostFree(P->staging[t]);
     if (P->copy_stream[t]) (void)hipStreamDestroy(P->copy_stream[t]);
@@ -376,11 +377,67 @@ int vs_synth(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples
 /* ------------------------------------------------------------------------------------------
  * vs_source / vs_filter: what the two drop-in programs call (one utterance, or small batches)
  * ---------------------------------------------------------------------------------------- */
+/* A handful of utterances -- what the two drop-in programs ask for: nothing is copied.  The plan's records, the flow
+ * that comes in, the PCM, the cycle log and the counts all live in pinned, device-mapped host memory; the kernel
+ * reads and writes them over PCIe (a few tens of KiB), the CPU moves rows between that block and the caller's
+ * buffers.  A process that only ever does this never triggers the runtime's copy-path set-up (27 ms). */
+#define VS_ZERO_COPY_LANES 64
+#define VS_ZERO_COPY_BYTES ((size_t)2 << 20)
+static int vs_run_host_zero_copy(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lanes,
+                                 size_t n_samples, const int16_t *in_host, int16_t *out_host,
+                                 vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
+{
+  VsPool *P = &ctx->pool;
+  const size_t pitch = (n_samples + 7) & ~(size_t)7; /* rows start 16-byte aligned */
+  const size_t bytes = n_lanes * pitch * sizeof(int16_t);
+  const bool want_log = recs && kind != VS_KIND_FILTER;
+  const bool want_ncyc = ncyc && kind != VS_KIND_FILTER;
+  const size_t log_bytes = want_log ? n_lanes * recs_pitch * sizeof(vs_cycle_rec) : 0;
+  const size_t ncyc_bytes = want_ncyc ? n_lanes * sizeof(int32_t) : 0;
+  const size_t off_in = (bytes + 63) & ~(size_t)63;
+  const size_t off_log = off_in + ((kind == VS_KIND_FILTER) ? ((bytes + 63) & ~(size_t)63) : 0);
+  const size_t off_ncyc = (off_log + log_bytes + 63) & ~(size_t)63;
+  const size_t total = off_ncyc + ncyc_bytes + 64;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  if (P->zc_io_bytes < total) {
+    if (P->zc_io) VS_HIP(ctx, hipHostFree(P->zc_io));
+    P->zc_io = NULL;
+    P->zc_io_bytes = 0;
+    const size_t want = (total + 65535) & ~(size_t)65535;
+    VS_HIP(ctx, hipHostMalloc(&P->zc_io, want, hipHostMallocMapped));
+    P->zc_io_bytes = want;
+  }
+  void *devp = NULL;
+  VS_HIP(ctx, hipHostGetDevicePointer(&devp, P->zc_io, 0));
+  char *hb = (char *)P->zc_io, *db = (char *)devp;
+  vs_plan *plan = NULL;
+  int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples,
+                               (kind == VS_KIND_FILTER ? VS_PLAN_FILTER_ONLY : 0) | VS_PLAN_POOL_SCRATCH | VS_PLAN_ZERO_COPY, &plan);
+  if (rc != VS_OK) return rc;
+  if (kind == VS_KIND_FILTER)
+    for (size_t l = 0; l < n_lanes; l++) memcpy(hb + off_in + l * pitch * 2, in_host + l * n_samples, n_samples * 2);
+  if (want_log) memset(hb + off_log, 0, log_bytes);
+  rc = vs_plan_launch(plan, kind, (kind == VS_KIND_FILTER) ? (const int16_t *)(db + off_in) : NULL, pitch, (int16_t *)db, pitch,
+                      want_log ? (vs_cycle_rec *)(db + off_log) : NULL, recs_pitch, want_ncyc ? (int32_t *)(db + off_ncyc) : NULL);
+  if (rc == VS_OK) rc = vs_plan_status(plan, NULL); /* waits for the stream: the device's writes are in host memory */
+  if (rc == VS_OK) {
+    for (size_t l = 0; l < n_lanes; l++) memcpy(out_host + l * n_samples, hb + l * pitch * 2, n_samples * 2);
+    if (want_log) memcpy(recs, hb + off_log, log_bytes);
+    if (want_ncyc) memcpy(ncyc, hb + off_ncyc, ncyc_bytes);
+  }
+  vs_plan_destroy(plan);
+  return rc;
+}
+
 static int vs_run_host(vs_ctx *ctx, int kind, const vs_lane *lanes, size_t n_lanes,
                        size_t n_samples, const int16_t *in_host, int16_t *out_host,
                        vs_cycle_rec *recs, size_t recs_pitch, int32_t *ncyc)
 {
   if (!ctx || !lanes || !out_host || n_lanes == 0 || n_samples == 0) return VS_ERR_ARG;
+  if (n_lanes <= VS_ZERO_COPY_LANES && !ctx->copy_warm &&
+      n_lanes * ((n_samples + 7) & ~(size_t)7) * 2 * (kind == VS_KIND_FILTER ? 2 : 1) +
+              (recs ? n_lanes * recs_pitch * sizeof(vs_cycle_rec) : 0) <= VS_ZERO_COPY_BYTES)
+    return vs_run_host_zero_copy(ctx, kind, lanes, n_lanes, n_samples, in_host, out_host, recs, recs_pitch, ncyc);
   VsPool *P = &ctx->pool;
   vs_plan *plan = NULL;
   int rc = vs_plan_create_impl(ctx, lanes, n_lanes, n_samples,

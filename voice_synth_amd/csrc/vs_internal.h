@@ -36,6 +36,8 @@ typedef struct VsPool {
   hipStream_t upload_stream;  /* lane records + cos rows of the NEXT chunk's plan, while this chunk's kernel runs */
   hipEvent_t done[2];       /* kernel of the chunk in d_out[k] has finished */
   int streams_ready;
+  void *zc_io;              /* small calls (vs_source / vs_filter of a few utterances: the drop-in programs): PCM in and out, */
+  size_t zc_io_bytes;       /* cycle log and counts in ONE block of pinned, device-mapped host memory -- no copy at all */
 } VsPool;
 
 struct vs_ctx {
@@ -48,6 +50,8 @@ struct vs_ctx {
   int cu_count;
   vs_tuning tuning; /* all zero = the library's own choices */
   VsPool pool;
+  int copy_warm;          /* the runtime's copy path has been set up (vs_copy_path_warm) */
+  double copy_warm_ms;    /* ... and what that cost */
   /* where the hardware deals the wavefronts of a workgroup (vs_ctx_simd_dealing): asked once, the first time a
    * plan wants a layout that is built on it */
   int simd_probed;        /* 0: not yet; 1: done; -1: the probe itself failed (treated as "not cyclic") */
@@ -87,6 +91,8 @@ struct vs_plan {
   size_t flow_pitch;
   int owns_flow;     /* d_flow was allocated for this plan (else: the context pool's, shared by the pipeline's chunk plans) */
   vs_tuning tuning;  /* the context's tuning when the plan was made */
+  void *zc_host;     /* zero-copy plans: lane records, cos rows, error word (and wide taps) in one pinned, device-mapped host block */
+  int *zc_err;       /* ... the error word as the host sees it */
   double host_ms;    /* host time of vs_plan_create: expansion, sorting, tables */
   double upload_ms;  /* ... and of the allocation + upload + wait that follows */
 };
@@ -121,6 +127,13 @@ double vs_now_ms(void);
 #define VS_PLAN_FILTER_ONLY 1  /* made by vs_filter(): no source records, no ring, VS_KIND_FILTER launches only */
 #define VS_PLAN_POOL_SCRATCH 2 /* chunk plans of a pipeline: launches are serial on one stream, so a wide plan's
                                   flow buffer is the context pool's instead of one allocation per chunk */
+#define VS_PLAN_ZERO_COPY 4    /* a handful of utterances (the drop-in programs): the plan's records live in pinned,
+                                  device-mapped host memory and the kernel reads them over PCIe -- no hipMemcpy, so a
+                                  process that only ever makes such plans never pays the 27 ms the runtime takes to set
+                                  up its copy path (profiles/r05_cli_startup.txt) */
+/* the runtime's first host-to-device copy sets up its copy path (27 ms, whatever the size); paid once per context,
+ * outside the plan's own timing, the first time a plan that copies is made */
+int vs_copy_path_warm(vs_ctx *ctx);
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                         int mode, vs_plan **out);
 /* bookkeeping of a node's gather (csrc/vs_host.c, plain C): the cut of a batch over the shards and the rows
