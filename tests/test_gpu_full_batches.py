@@ -47,17 +47,22 @@ def test_full_batch_blended_pole_sets_every_sample(engine):
     assert bad == 0
 
 
-@pytest.mark.parametrize("index,n,kernel", [(3, 65536, "vs_synth_ws_kernel<0, true, 3>"), (3, 65536 - 219, "vs_synth_ws_kernel<0, true, 3>"),
-                                            (5, 65536 - 219, "vs_synth_ws_kernel<0, true, 2>")])
-def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel):
+@pytest.mark.parametrize("index,n,kernel,mixed", [(3, 65536, "vs_synth_ws_kernel<0, true, 3>", 0), (3, 65536 - 219, "vs_synth_ws_kernel<0, true, 3>", 0),
+                                                  (5, 65536 - 219, "vs_synth_ws_kernel<0, true, 3>", 0), (5, 65536, "vs_synth_ws_kernel<0, true, 3>", 0),
+                                                  (5, 65536 - 219, "vs_synth_ws_kernel<0, true, 2>", -1)])
+def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel, mixed):
     """what bench.py times -- ONE launch of the plan of the whole batch (the tests above go through the
     delivery pipeline, i.e. plans of 16384 utterances, which never take the full-grid kernels): the
     three-role kernel on config 3, with a last group of 37 utterances and three empty groups behind it in
-    its workgroup (their stores go to the sink row), and the two-role kernel on the full grid of config 5"""
+    its workgroup; config 5's F0 sweep over MIXED rings (every workgroup holds groups from across the period range, each
+    with the ring depth its periods need: three roles everywhere), with a ragged last group and whole; and the same sweep
+    over uniform rings (vs_tuning.mixed_rings = -1): the two-role kernel with the divergent filter loop"""
     specs, fs, dur, label = configs.config_specs(index, n)
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
+    engine.set_tuning(mixed_rings=mixed) if mixed else engine.set_tuning()
     plan = engine.plan(lanes, ns)
+    engine.set_tuning()
     out = engine.dev_alloc(n * ns * 2)
     try:
         assert plan.kernel_name(vs.VS_KIND_SYNTH) == kernel

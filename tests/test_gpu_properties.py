@@ -139,7 +139,8 @@ def test_longest_period_of_the_wide_ring_and_beyond(engine):
 def test_which_fused_kernel_a_plan_takes(engine):
     """the roles of the wave-specialised kernel are chosen by the shape of the work, not by what happens to
     fit the LDS: three (open phase | noise | filter) on a full grid of deep rings with glottal noise
-    (BASELINE config 3), two where the rings hold barely a cycle (config 5's F0 sweep: a filter wavefront
+    (BASELINE config 3; config 5's F0 sweep too, once every group has the ring depth ITS periods need -- mixed rings),
+    two where the rings hold barely a cycle (the F0 sweep over uniform rings: a filter wavefront
     that waits for all of its lanes starves there), where there is no glottal noise (config 2's shape),
     and three again on half-filled chips with glottal noise (config 4's shard: the filter wavefront alone on its
     SIMD, open phase and noise together on the next; a 16384-utterance chunk: a SIMD per wavefront)."""
@@ -151,7 +152,12 @@ def test_which_fused_kernel_a_plan_takes(engine):
         plan.close()
         return name
     assert kernel(3, 65536) == "vs_synth_ws_kernel<0, true, 3>"
-    assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 3>"
+    engine.set_tuning(mixed_rings=-1)
+    try:
+        assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 2>"
+    finally:
+        engine.set_tuning()
     assert kernel(2, 65536) == "vs_synth_ws_kernel<0, true, 2>"
     assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 3>"
     assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 3>"   # a chunk of the delivery pipelines

@@ -139,6 +139,7 @@ class Tuning(C.Structure):
         ("fault", C.c_int32),
         ("ws_filter_prio", C.c_int32),
         ("ws_roles", C.c_int32),
+        ("mixed_rings", C.c_int32),
     ]
 
 

@@ -62,6 +62,7 @@ int vs_ctx_create(int device, vs_ctx **out)
       if ((v = getenv("VS_WS_ROLES")) != NULL) t.ws_roles = atoi(v);
       if ((v = getenv("VS_GEN_LOW")) != NULL) t.gen_low = atoi(v);
       if ((v = getenv("VS_GEN_MIN")) != NULL) t.gen_min = atoi(v);
+      if ((v = getenv("VS_MIXED_RINGS")) != NULL) t.mixed_rings = (atoi(v) == 0) ? -1 : 0;
       if ((v = getenv("VS_WS_PRIO")) != NULL) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
       if (vs_ctx_set_tuning(ctx, &t) != VS_OK) {
         free(ctx);
@@ -123,6 +124,7 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->fault < 0 || t->fault > VS_FAULT_SIMD_DEALING) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
+  if (t->mixed_rings != 0 && t->mixed_rings != -1) return VS_ERR_ARG;
   ctx->tuning = *t;
   return VS_OK;
 }
@@ -315,6 +317,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   size_t costab_len = 0, costab_cap = 0;
   int *row_of_T2 = NULL;   /* first entry of the row of T2 in costab, -1: not built yet */
   double *awide = NULL;    /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
+  VsGroupSlot *gmap = NULL; /* mixed rings: which group, which ring depth, which LDS region per (workgroup, slot) */
   vs_plan *p = NULL;
   if (!dl) return VS_ERR_NOMEM;
   const double t_host0 = vs_now_ms();
@@ -456,6 +459,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   size_t lds_bytes = 0;
   int ws_pairs = 1, ws_pair_bytes = 0, ws_roles = 2, ws_layout = VS_WS_LAYOUT_ROLE_MAJOR, simd_fallback = 0;
   bool all_deep = true; /* every group's ring holds 1.65 of its longest cycles or more (see the thresholds below) */
+  size_t n_wg_mixed = 0, mixed_lds = 0; /* mixed rings (below): gmap is [n_wg_mixed][4] */
+  int mixed_c_min = 0;
   if (!filter_only) {
     /* Half-filled chips (at most two groups per CU) have LDS to spare: rings of 2.4 of the longest cycle instead of
      * 1.7.  With a SIMD per wavefront nobody fills the gaps a starved filter wavefront leaves, and a deeper ring is what
@@ -487,9 +492,87 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       if (wave_specialised) thr = (rho >= 1.65) ? 64 : (ws_shared_simd ? 48 : 40);
       for (size_t l = w0; l < n_lanes && l < w0 + G; l++) dl[l].ready_min = thr;
     }
+    /* Mixed rings.  A full grid whose groups differ in period (BASELINE config 5's F0 sweep: P = 53 .. 200) and a
+     * uniform ring sized for the longest of them: the long-period groups get barely one cycle (rho 1.1), their filter
+     * cannot wait for all lanes, the plan falls back to two roles with the divergent filter loop -- while the
+     * short-period groups sit on five cycles' worth of LDS they do not need.  Instead: every group gets the depth ITS
+     * periods need (1.7 cycles), and a workgroup is put together from groups ACROSS the period range (sorted by
+     * period, dealt to the workgroups in snake order: the longest with the shortest), so that the four rings of a
+     * workgroup share the CU's LDS unevenly and still fit.  Every group is deep then, the three-role kernel with the
+     * all-lanes filter loop runs everywhere (VsGroupSlot, vs_device.h). */
+    if (wave_specialised && !all_deep && ws_shared_simd && group_lanes == VS_WAVE && tune->ring_slots == 0 &&
+        tune->mixed_rings == 0 && (tune->ws_pairs == 0 || tune->ws_pairs == 4)) {
+      const size_t n_groups = grid, n_wg = (n_groups + 3) / 4;
+      int *tb_g = (int *)malloc(n_groups * sizeof(int));
+      uint32_t *order = (uint32_t *)malloc(n_groups * sizeof(uint32_t));
+      gmap = (VsGroupSlot *)calloc(n_wg * 4, sizeof(VsGroupSlot));
+      size_t *used = (size_t *)calloc(n_wg, sizeof(size_t));
+      bool ok = tb_g && order && gmap && used;
+      const size_t fixed = (size_t)ltab_entries * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int);
+      int c_min = 0, c_max = 0;
+      if (ok) {
+        for (size_t g = 0; g < n_groups; g++) {
+          int tb = 1;
+          for (size_t l = g * G; l < n_lanes && l < (g + 1) * G; l++)
+            if ((int)dl[l].tbound > tb) tb = (int)dl[l].tbound;
+          tb_g[g] = tb;
+          order[g] = (uint32_t)g;
+        }
+        /* groups by longest period, descending (the records are sorted by period already: a stable insertion over
+         * a nearly reversed sequence would be quadratic -- the groups' order IS ascending, so walk it backwards,
+         * and only fix what the cut into groups of 64 may have disturbed) */
+        for (size_t g = 0; g < n_groups; g++) order[g] = (uint32_t)(n_groups - 1 - g);
+        for (size_t i = 1; i < n_groups; i++) {
+          const uint32_t v = order[i];
+          size_t k = i;
+          while (k > 0 && tb_g[order[k - 1]] < tb_g[v]) {
+            order[k] = order[k - 1];
+            k--;
+          }
+          order[k] = v;
+        }
+        for (size_t i = 0; i < n_wg * 4; i++) gmap[i].group = -1;
+        for (size_t i = 0; i < n_groups && ok; i++) {
+          const size_t pass = i / n_wg, pos = i % n_wg;
+          const size_t wg = (pass & 1) ? (n_wg - 1 - pos) : pos; /* snake */
+          const int tb = tb_g[order[i]];
+          int c = ((VS_SS + (int)(1.7 * tb) + VS_SS - 1) / VS_SS) * VS_SS;
+          const int need = ((VS_SS + tb + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
+          if (c < 144) c = 144;
+          if (c < need) c = need;
+          if ((double)(c - VS_SS) / (double)tb < 1.65) c += VS_SS;
+          const size_t bytes = (((size_t)(c + VS_TRASH_ROWS) * G * sizeof(int16_t) + fixed) + 15) & ~(size_t)15;
+          VsGroupSlot *gs = &gmap[wg * 4 + pass];
+          gs->group = (int32_t)order[i];
+          gs->ring_slots = c;
+          gs->lds_off = (int32_t)used[wg];
+          used[wg] += bytes;
+          if (used[wg] > VS_LDS_LIMIT) ok = false;
+          if (c_min == 0 || c < c_min) c_min = c;
+          if (c > c_max) c_max = c;
+        }
+      }
+      if (ok) {
+        for (size_t w = 0; w < n_wg; w++)
+          if (used[w] > mixed_lds) mixed_lds = used[w];
+        for (size_t l = 0; l < n_lanes; l++) dl[l].ready_min = 64; /* every ring is deep: the filter waits for all of its lanes */
+        all_deep = true;
+        slots = c_max;
+        mixed_c_min = c_min;
+        n_wg_mixed = n_wg;
+      } else {
+        free(gmap);
+        gmap = NULL;
+      }
+      free(tb_g);
+      free(order);
+      free(used);
+    }
     ready_min = tune->ready_min > 0 ? tune->ready_min : 0; /* 0: the groups' own thresholds */
     /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
-    lds_bytes = (size_t)(slots + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+    /* (mixed rings: what one group WOULD take at the uniform depth of the shallowest ring -- the shape decisions below
+     * see a group that fits four to a workgroup, which is what the table guarantees; the launch takes the table's sum) */
+    lds_bytes = (size_t)((gmap ? mixed_c_min : slots) + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
     if (lds_bytes > VS_LDS_LIMIT) {
       rc = VS_ERR_UNSUPPORTED;
       goto done;
@@ -503,6 +586,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       ws_pairs = (grid <= cus) ? 1 : (grid <= 2u * cus ? 2 : 4);
       if (tune->ws_pairs > 0) ws_pairs = tune->ws_pairs;
       while (ws_pairs > 1 && (size_t)ws_pairs * (size_t)ws_pair_bytes > VS_LDS_LIMIT) ws_pairs >>= 1;
+      if (gmap) ws_pairs = 4; /* the table's shape; it was checked against the LDS group by group */
       /* Full grids (four groups per workgroup, the wavefronts of a group share a SIMD): three roles
        * -- open phase | noise | filter -- if the extra progress words and order boxes still fit next
        * to four rings.  Otherwise two: generator | filter. */
@@ -514,7 +598,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * deep rings: the filter wavefront of the three-role kernel waits for ALL of its lanes, which a
        * ring of barely one cycle cannot feed (BASELINE config 5's F0 sweep: 4.4 ms against 3.66 with two
        * roles, profiles/r03_kernel_experiments.txt) */
-      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && all_deep && (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT)
+      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && all_deep && (gmap || (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT))
         ws_roles = 3;
       /* Half-filled chips (one or two groups per workgroup: BASELINE config 4's shard, the 16384-utterance chunks
        * of the pipelines): the lone filter wavefront is the bound and the one generator wavefront next door takes
@@ -526,7 +610,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       if (wave_specialised && ws_pairs <= 2 && 2 * noisy >= n_lanes && all_deep && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)
         ws_roles = 3;
       if (tune->ws_roles == 2) ws_roles = 2;
-      if (tune->ws_roles == 3 && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT) ws_roles = 3;
+      if (tune->ws_roles == 3 && (gmap || (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)) ws_roles = 3;
       /* Both three-role layouts are built on "wavefront w runs on the SIMD of wavefront w % 4": role-major puts the three wavefronts
        * of ONE group on one SIMD (12 wavefronts), the spread layout keeps the filter wavefront alone (8).  Asked of
        * the hardware once per context (a probe launch, vs_ctx_simd_dealing); where it does not hold, two roles --
@@ -541,6 +625,16 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       }
       if (ws_roles == 3) ws_pair_bytes = bytes3;
       if (ws_roles == 3 && ws_pairs == 2) ws_layout = VS_WS_LAYOUT_SPREAD_2X3;
+      /* the mixed-rings table was laid out for four groups per workgroup with the progress words of three roles
+       * (two roles use fewer of them); any other shape: not built for it */
+      if (gmap && ws_pairs != 4) {
+        rc = VS_ERR_INTERNAL; /* cannot happen: the table is only made for full grids, which take four groups per workgroup */
+        goto done;
+      }
+    }
+    if (gmap && !wave_specialised) {
+      rc = VS_ERR_INTERNAL;
+      goto done;
     }
   }
 
@@ -555,7 +649,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->ring_slots = slots;
   p->ready_min = ready_min;
   p->ltab_entries = ltab_entries;
-  p->lds_bytes = lds_bytes;
+  p->lds_bytes = gmap ? mixed_lds : lds_bytes;
+  p->ring_slots_min = gmap ? mixed_c_min : slots;
   p->grid = grid;
   p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
@@ -602,6 +697,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
   }
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
+  if (e == hipSuccess && gmap) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
   if (e == hipSuccess && wide && !filter_only) {
@@ -629,6 +725,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       e = hipMemcpyAsync(p->d_lanes, dl, n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
     if (e == hipSuccess && costab_len)
       e = hipMemcpyAsync(p->d_costab, costab, costab_len * sizeof(double), hipMemcpyHostToDevice, up);
+    if (e == hipSuccess && gmap)
+      e = hipMemcpyAsync(p->d_group_map, gmap, n_wg_mixed * 4 * sizeof(VsGroupSlot), hipMemcpyHostToDevice, up);
     if (e == hipSuccess) e = hipStreamSynchronize(up);
   }
   if (e != hipSuccess) {
@@ -648,6 +746,7 @@ done:
   free(costab);
   free(row_of_T2);
   free(awide);
+  free(gmap);
   return rc;
 }
 
@@ -670,6 +769,7 @@ void vs_plan_destroy(vs_plan *p)
     if (p->d_awide) (void)hipFree(p->d_awide);
   }
   if (p->d_sink) (void)hipFree(p->d_sink);
+  if (p->d_group_map) (void)hipFree(p->d_group_map);
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   free(p);
@@ -783,6 +883,7 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   a.ws_pairs = p->ws_pairs;
   a.ws_roles = p->ws_roles;
   a.ws_layout = p->ws_layout;
+  a.group_map = p->d_group_map;
   a.group_lanes = p->group_lanes;
   a.ws_pair_bytes = p->ws_pair_bytes;
   /* a generator round starts when gen_min/64 of the lanes that still need cycles have room -- or at

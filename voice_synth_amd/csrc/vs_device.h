@@ -59,6 +59,17 @@ typedef struct VsDevLane {
   int32_t ready_min;  /* super-step threshold of this lane's 64-utterance group (the same in all its lanes): ready lanes * 64 >= live lanes * ready_min */
 } VsDevLane;
 
+/* Wave-specialised launches whose groups differ in period (an F0 sweep): one record per (workgroup, slot) -- which
+ * 64-utterance group the slot serves, how many ring slots it has and where its LDS starts.  A workgroup then holds
+ * groups from ACROSS the period range, the short-period ones lending LDS to the long-period ones, so that every ring
+ * holds >= 1.65 of its group's longest cycles (vs_plan_create_impl: "mixed rings"). */
+typedef struct VsGroupSlot {
+  int32_t group;      /* index of the 64-utterance group (lanes [64*group, 64*group + 64) of the sorted records); -1: none */
+  int32_t ring_slots; /* C of this group's ring (multiple of VS_SS) */
+  int32_t lds_off;    /* byte offset of the group's LDS region in the workgroup's allocation (16-byte multiple) */
+  int32_t reserved;
+} VsGroupSlot;
+
 typedef struct VsKernelArgs {
   const VsDevLane *lanes;
   const double *costab;
@@ -89,6 +100,7 @@ typedef struct VsKernelArgs {
   int16_t *sink;       /* one row of n_samples + 32 samples nobody reads: where the lanes beyond n_lanes of the last group store (wave-specialised kernels) */
   const double *awide; /* wide plans (a coefficient set of 23..40 taps): A[1..40] per lane record, zeros behind its order */
   int ws_layout;       /* wave-specialised kernels, how a workgroup's wavefronts map to roles: VS_WS_LAYOUT_* */
+  const VsGroupSlot *group_map; /* mixed rings: [workgroups][ws_pairs]; NULL: group = workgroup * ws_pairs + slot, uniform rings */
 } VsKernelArgs;
 
 /* Wavefronts of a workgroup are dealt to the CU's four SIMDs four at a time: wavefront w runs on the SIMD of wavefront

@@ -79,6 +79,8 @@ struct vs_plan {
   int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
   int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */
   int ws_layout;     /* VS_WS_LAYOUT_* (VsKernelArgs.ws_layout) */
+  VsGroupSlot *d_group_map; /* mixed rings: [workgroups][ws_pairs] on the device, NULL for uniform rings */
+  int ring_slots_min;       /* mixed rings: the shallowest ring of the plan (ring_slots holds the deepest) */
   int simd_fallback; /* the plan wanted three roles and took two because the wavefronts are not dealt four at a time */
   int ws_shared_simd; /* the wavefronts of a group share a SIMD (grids beyond two groups per CU) */
   int group_lanes;   /* utterances per wavefront: VS_WAVE, or VS_NARROW_LANES for periods beyond the 64-column ring */

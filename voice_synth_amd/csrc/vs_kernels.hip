@@ -679,12 +679,20 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
   VsGroup g;
   g.lane = (int)threadIdx.x & (VS_WAVE - 1);
   g.group = (long)blockIdx.x * (long)ngroups + slot;
+  g.C = args.ring_slots;
+  g.ring = lds_base + (size_t)slot * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
+  if (args.group_map) {
+    /* mixed rings (vs_device.h, VsGroupSlot): this slot's group, ring depth and LDS region come from the plan's
+     * table -- one scalar load, everything stays wave-uniform */
+    const VsGroupSlot gs = args.group_map[(size_t)blockIdx.x * (size_t)ngroups + (size_t)slot];
+    g.group = (gs.group >= 0) ? (long)gs.group : (((long)args.n_lanes + VS_WAVE - 1) / VS_WAVE); /* none: beyond the batch */
+    g.C = __builtin_amdgcn_readfirstlane(gs.ring_slots);
+    g.ring = lds_base + (size_t)__builtin_amdgcn_readfirstlane(gs.lds_off) / sizeof(int16_t);
+  }
   const long gl = g.group * VS_WAVE + g.lane;
   g.valid = gl < (long)args.n_lanes;
   g.L = args.lanes + (g.valid ? gl : (long)args.n_lanes - 1);
   g.N = args.n_samples;
-  g.C = args.ring_slots;
-  g.ring = lds_base + (size_t)slot * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
   g.ltab = (double *)(g.ring + (size_t)(g.C + VS_TRASH_ROWS) * VS_WAVE);
   g.gpub = (int *)(g.ltab + args.ltab_entries);
   g.npub = g.gpub + VS_WAVE;
@@ -703,6 +711,9 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
   }
   __syncthreads();
   if (role < 0) return; /* the two spare wavefronts of the spread layout */
+  /* a slot without a group (the last workgroup of a grid that is no multiple of its groups; an empty slot of the
+   * mixed-rings table): nothing to synthesise -- its filter wavefront used to run all N samples into the sink row */
+  if (g.group * VS_WAVE >= (long)args.n_lanes) return;
 
 #ifdef VS_TIMING_GENERATOR_ONLY
   if (role == ROLES - 1) return;
@@ -1134,7 +1145,10 @@ extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_sp
       if (args->ws_pairs != 2) return hipErrorInvalidValue;
       block = 8 * VS_WAVE;
     }
-    lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
+    /* mixed rings (args->group_map): the rings of a workgroup differ in depth and lds_bytes arrives as the largest
+     * workgroup's sum */
+    if (!args->group_map) lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
+    else if (args->ws_pairs != 4 || (three && args->ws_layout != VS_WS_LAYOUT_ROLE_MAJOR)) return hipErrorInvalidValue;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
   } else
 #endif
