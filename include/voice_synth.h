@@ -214,7 +214,8 @@ typedef struct vs_tuning {
   int32_t ws_roles;   /* wavefronts per 64 utterances of the wave-specialised launch: 0 = the library's choice,
                          2 = generator | filter, 3 = open phase | noise | filter (full grids) */
   int32_t mixed_rings; /* batches whose groups differ in period: 0 = the library's choice (a workgroup holds groups from
-                          across the period range, each with the ring depth ITS periods need), -1 = never (uniform rings) */
+                          across the period range, each with the ring depth ITS periods need), -1 = never (uniform rings),
+                          > 1 = the same with this many slots as the shallowest ring (measurements) */
 } vs_tuning;
 int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
 /* Device self-test of the arithmetic shortcuts the kernels take: [0] division shortcut

@@ -79,3 +79,17 @@ def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel, mi
         bad += int((got[lo:hi] != po.synth([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
     print("%s, one launch of %d utterances: %d of %d samples differ" % (label, n, bad, got.size))
     assert bad == 0
+
+
+def test_full_grid_of_random_utterances_over_mixed_rings():
+    """one launch of ~40000 random utterances (F0 60-400 Hz, every option drawn at random, most with glottal noise): a
+    full grid whose groups differ in period, i.e. the mixed-rings plan -- groups from across the period range share a
+    workgroup, each with the ring depth its periods need -- and whatever roles it picks; every sample against the oracle"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_fullgrid
+    k, bad, st, name, info = fuzz_fullgrid.run(4242, 42000, 3000)
+    print("%d lanes, %s, %s" % (k, name, info))
+    assert k > 33000 and st == 0 and bad == 0
+    assert name.startswith("vs_synth_ws_kernel") and info["lds_bytes"] > 64 * 1024     # mixed rings: several rings per workgroup

@@ -62,7 +62,7 @@ int vs_ctx_create(int device, vs_ctx **out)
       if ((v = getenv("VS_WS_ROLES")) != NULL) t.ws_roles = atoi(v);
       if ((v = getenv("VS_GEN_LOW")) != NULL) t.gen_low = atoi(v);
       if ((v = getenv("VS_GEN_MIN")) != NULL) t.gen_min = atoi(v);
-      if ((v = getenv("VS_MIXED_RINGS")) != NULL) t.mixed_rings = (atoi(v) == 0) ? -1 : 0;
+      if ((v = getenv("VS_MIXED_RINGS")) != NULL) t.mixed_rings = (atoi(v) == 0) ? -1 : (atoi(v) == 1 ? 0 : atoi(v));
       if ((v = getenv("VS_WS_PRIO")) != NULL) t.ws_filter_prio = (atoi(v) == 0) ? -1 : atoi(v);
       if (vs_ctx_set_tuning(ctx, &t) != VS_OK) {
         free(ctx);
@@ -124,7 +124,7 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->fault < 0 || t->fault > VS_FAULT_SIMD_DEALING) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
-  if (t->mixed_rings != 0 && t->mixed_rings != -1) return VS_ERR_ARG;
+  if (t->mixed_rings < -1 || t->mixed_rings > 4096) return VS_ERR_ARG;
   ctx->tuning = *t;
   return VS_OK;
 }
@@ -501,21 +501,34 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
      * workgroup share the CU's LDS unevenly and still fit.  Every group is deep then, the three-role kernel with the
      * all-lanes filter loop runs everywhere (VsGroupSlot, vs_device.h). */
     if (wave_specialised && !all_deep && ws_shared_simd && group_lanes == VS_WAVE && tune->ring_slots == 0 &&
-        tune->mixed_rings == 0 && (tune->ws_pairs == 0 || tune->ws_pairs == 4)) {
+        tune->mixed_rings >= 0 && (tune->ws_pairs == 0 || tune->ws_pairs == 4)) {
+      /* the shallowest ring: 192 slots if the workgroups can afford it (short periods hand over often -- eight
+       * super-steps of room instead of six are worth 4 % on config 5, tools/sweep5.sh), else 168, else 144 */
+      int floor_slots = tune->mixed_rings > 1 ? ((tune->mixed_rings + VS_SS - 1) / VS_SS) * VS_SS : 192;
+    retry_floor:;
       const size_t n_groups = grid, n_wg = (n_groups + 3) / 4;
       int *tb_g = (int *)malloc(n_groups * sizeof(int));
       uint32_t *order = (uint32_t *)malloc(n_groups * sizeof(uint32_t));
       gmap = (VsGroupSlot *)calloc(n_wg * 4, sizeof(VsGroupSlot));
       size_t *used = (size_t *)calloc(n_wg, sizeof(size_t));
       bool ok = tb_g && order && gmap && used;
-      const size_t fixed = (size_t)ltab_entries * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int);
+      int *ltab_g = (int *)malloc(n_groups * sizeof(int)); /* every group reserves what ITS cos rows take */
+      ok = ok && ltab_g;
       int c_min = 0, c_max = 0;
       if (ok) {
         for (size_t g = 0; g < n_groups; g++) {
-          int tb = 1;
-          for (size_t l = g * G; l < n_lanes && l < (g + 1) * G; l++)
+          int tb = 1, seen[VS_WAVE], nseen = 0, sum = 0;
+          for (size_t l = g * G; l < n_lanes && l < (g + 1) * G; l++) {
             if ((int)dl[l].tbound > tb) tb = (int)dl[l].tbound;
+            bool dup = false;
+            for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
+            if (!dup) {
+              seen[nseen++] = dl[l].T2;
+              sum += (dl[l].T2 + 7) & ~7;
+            }
+          }
           tb_g[g] = tb;
+          ltab_g[g] = sum; /* multiples of 8 doubles */
           order[g] = (uint32_t)g;
         }
         /* groups by longest period, descending (the records are sorted by period already: a stable insertion over
@@ -538,13 +551,15 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
           const int tb = tb_g[order[i]];
           int c = ((VS_SS + (int)(1.7 * tb) + VS_SS - 1) / VS_SS) * VS_SS;
           const int need = ((VS_SS + tb + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
-          if (c < 144) c = 144;
+          if (c < floor_slots) c = floor_slots;
           if (c < need) c = need;
           if ((double)(c - VS_SS) / (double)tb < 1.65) c += VS_SS;
+          const size_t fixed = (size_t)ltab_g[order[i]] * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int);
           const size_t bytes = (((size_t)(c + VS_TRASH_ROWS) * G * sizeof(int16_t) + fixed) + 15) & ~(size_t)15;
           VsGroupSlot *gs = &gmap[wg * 4 + pass];
           gs->group = (int32_t)order[i];
           gs->ring_slots = c;
+          gs->ltab_entries = ltab_g[order[i]];
           gs->lds_off = (int32_t)used[wg];
           used[wg] += bytes;
           if (used[wg] > VS_LDS_LIMIT) ok = false;
@@ -565,8 +580,13 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
         gmap = NULL;
       }
       free(tb_g);
+      free(ltab_g);
       free(order);
       free(used);
+      if (!gmap && tune->mixed_rings <= 1 && floor_slots > 144) {
+        floor_slots -= VS_SS;
+        goto retry_floor;
+      }
     }
     ready_min = tune->ready_min > 0 ? tune->ready_min : 0; /* 0: the groups' own thresholds */
     /* ring rows + the trash rows (lanes that must not emit write there) + the cos rows */
@@ -899,6 +919,13 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   if (p->ws_roles == 3 && p->ws_pairs <= 2) {
     if (p->tuning.gen_min <= 0) a.gen_min = 48;
     if (p->tuning.gen_low <= 0) a.gen_low = 144;
+  }
+  /* three roles over mixed rings (an F0 sweep): the short-period groups hand over twice as often per sample as
+   * config 3's and their rings are shallow in SAMPLES (192 slots = 8 super-steps): a round starts for three quarters of
+   * the lanes, and at once for a lane that is down to two super-steps (tools/sweep5.sh: 3.36 -> 3.22 ms, same box) */
+  if (p->ws_roles == 3 && p->d_group_map) {
+    if (p->tuning.gen_min <= 0) a.gen_min = 48;
+    if (p->tuning.gen_low <= 0) a.gen_low = 48;
   }
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;

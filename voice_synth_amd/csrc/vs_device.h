@@ -67,7 +67,7 @@ typedef struct VsGroupSlot {
   int32_t group;      /* index of the 64-utterance group (lanes [64*group, 64*group + 64) of the sorted records); -1: none */
   int32_t ring_slots; /* C of this group's ring (multiple of VS_SS) */
   int32_t lds_off;    /* byte offset of the group's LDS region in the workgroup's allocation (16-byte multiple) */
-  int32_t reserved;
+  int32_t ltab_entries; /* doubles reserved behind THIS group's ring for its cos rows (a multiple of 2: the progress words behind them stay 16-byte aligned) */
 } VsGroupSlot;
 
 typedef struct VsKernelArgs {

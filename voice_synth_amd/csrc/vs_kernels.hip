@@ -312,6 +312,7 @@ struct VsGroup {
   VsOrderBox ord;
   long group, row;
   int lane, N, C;
+  int ltab_entries; /* doubles reserved for this group's cos rows (the launch's, or the group's own over mixed rings) */
   bool valid;
 };
 
@@ -332,7 +333,7 @@ __device__ __forceinline__ void vs_generator_wave(const VsKernelArgs &args, cons
   dg.t = vs_stamp();
 #endif
   vs_load_cfg(g.L, c, s);
-  vs_stage_cos_rows(g.L, c, g.ltab, args.costab, args.ltab_entries, lane, g.valid, args);
+  vs_stage_cos_rows(g.L, c, g.ltab, args.costab, g.ltab_entries, lane, g.valid, args);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* own staging writes before own row reads */
   VsRoundKeys rk; /* two roles: this wavefront draws the noise itself (three: the noise wavefront has its own) */
   if (!SPLIT) vs_round_keys(c.key0, c.key1, rk);
@@ -680,6 +681,7 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
   g.lane = (int)threadIdx.x & (VS_WAVE - 1);
   g.group = (long)blockIdx.x * (long)ngroups + slot;
   g.C = args.ring_slots;
+  g.ltab_entries = args.ltab_entries;
   g.ring = lds_base + (size_t)slot * (size_t)(args.ws_pair_bytes / sizeof(int16_t));
   if (args.group_map) {
     /* mixed rings (vs_device.h, VsGroupSlot): this slot's group, ring depth and LDS region come from the plan's
@@ -688,13 +690,14 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
     g.group = (gs.group >= 0) ? (long)gs.group : (((long)args.n_lanes + VS_WAVE - 1) / VS_WAVE); /* none: beyond the batch */
     g.C = __builtin_amdgcn_readfirstlane(gs.ring_slots);
     g.ring = lds_base + (size_t)__builtin_amdgcn_readfirstlane(gs.lds_off) / sizeof(int16_t);
+    g.ltab_entries = __builtin_amdgcn_readfirstlane(gs.ltab_entries);
   }
   const long gl = g.group * VS_WAVE + g.lane;
   g.valid = gl < (long)args.n_lanes;
   g.L = args.lanes + (g.valid ? gl : (long)args.n_lanes - 1);
   g.N = args.n_samples;
   g.ltab = (double *)(g.ring + (size_t)(g.C + VS_TRASH_ROWS) * VS_WAVE);
-  g.gpub = (int *)(g.ltab + args.ltab_entries);
+  g.gpub = (int *)(g.ltab + g.ltab_entries);
   g.npub = g.gpub + VS_WAVE;
   g.ord.oseq = g.npub + VS_WAVE;
   g.ord.otak = g.ord.oseq + VS_WAVE;
