@@ -63,9 +63,14 @@ __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDia
   VS_DIAG_ADD(dg, 0)
 }
 
-/* psum + (float)x*(float)x of flowgen_shimmer.c:376 for an integer sample |x| <= 32767: the
- * square is exact in 32-bit integers and its conversion rounds exactly as the float product. */
-__device__ __forceinline__ float vs_sq_f(int x) { return (float)__mul24(x, x); }
+/* (float)x*(float)x of flowgen_shimmer.c:376 for an integer sample |x| <= 32767, literally: the conversion is exact
+ * (16 bits into 24), the product rounds once.  (The integer form -- (float)(x*x), same value -- costs a V_MUL_I32_I24
+ * of the expensive class where V_MUL_F32 is a plain 32-bit operation: tools/ubench/ubench5.) */
+__device__ __forceinline__ float vs_sq_f(int x)
+{
+  const float f = (float)x;
+  return f * f;
+}
 
 /* Publishing progress through LDS: the LDS performs the operations of ONE wavefront in the order
  * they were issued, so a progress word stored after the data is seen after the data by whoever
