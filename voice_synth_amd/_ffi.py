@@ -248,6 +248,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     for table in (SYMBOLS, INTERNAL_SYMBOLS):
         for name, (res, args) in table.items():
+            if "VS_LIB" in os.environ and not hasattr(lib, name):
+                continue             # an A/B build of an earlier round (tools/): it simply lacks the newer entries
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args

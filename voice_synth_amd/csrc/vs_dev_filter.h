@@ -128,8 +128,17 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
          * order) instead of one in front of every sample's first use -- to a wavefront that issues an
          * instruction every ~5.3 ticks whatever it is, a wait that has nothing to wait for costs as much
          * as a multiplication (tools/ubench/ubench5.hip) */
-        asm volatile("" ::"v"(xin[t]), "v"(xin[t + 1]), "v"(xin[t + 2]), "v"(xin[t + 3]), "v"(xin[t + 4]), "v"(xin[t + 5]),
-                     "v"(xin[t + 6]), "v"(xin[t + 7]));
+        /* ... and the code behind it starts on an 8-byte boundary.  The super-step is a straight line of ~1300
+         * instructions, most of them 8 bytes long (fp64 arithmetic only has the 64-bit VOP3 encoding); the 4-byte ones
+         * come in pairs per sample (conversion + fused first difference, ceil + conversion), so a chunk of 8 samples
+         * is either in step with the 8-byte grid or out of it as a whole -- and an 8-byte instruction that straddles
+         * an 8-byte boundary costs a wavefront that is ALONE on its SIMD about one cycle of instruction fetch
+         * (half-filled chips: BASELINE config 4's shard, config 2; profiles/r05_loop_alignment.txt: the same loop
+         * took 4.58 or 4.82 ms, config 2 1.58 or 1.80 ms, depending on one 4-byte instruction more in the kernel's
+         * prologue).  What puts a chunk out of step is the lone 4-byte s_waitcnt in front of this statement (and the
+         * loop control in front of the first chunk): the assembler pads with one s_nop when it has. */
+        asm volatile(".p2align 3" ::"v"(xin[t]), "v"(xin[t + 1]), "v"(xin[t + 2]), "v"(xin[t + 3]), "v"(xin[t + 4]),
+                     "v"(xin[t + 5]), "v"(xin[t + 6]), "v"(xin[t + 7]));
       }
       /* y_double[0] = 0.0 + B[0]*x[i]*gain, B = {1, 0, ...} (vowel_new.c:266-269, 435-448) */
       double acc;
