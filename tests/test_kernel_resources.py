@@ -52,3 +52,24 @@ def test_no_kernel_of_the_library_uses_scratch(recs):
     """the one-wave kernels park registers in AGPRs (no scratch traffic); nothing else may spill to memory either"""
     for name, r in recs.items():
         assert r["scratch"] == 0, (name, r)
+
+
+def test_superstep_loops_are_in_step_with_the_8_byte_grid():
+    """A wavefront alone on its SIMD pays about one cycle for every 8-byte instruction that straddles an 8-byte boundary
+    (profiles/r05_loop_alignment.txt: config 4's shard 4.58 against 4.82 ms, config 2 1.58 against 1.80, for one 4-byte
+    instruction more in front of the loop).  The super-step keeps its chunks in step by itself (.p2align 3 behind each
+    chunk's s_waitcnt; the tolerance mode keeps the sign of its taps in the registers, so that its 21 multiply-adds per
+    sample are 4-byte V_FMAC_F64 with nothing to straddle); this looks at the BUILT code object: in every wave-specialised
+    instantiation at most 160 of the super-step's ~1160 8-byte instructions (exact; ~190 in the tolerance mode) sit off
+    the 8-byte grid -- the parity that cost 5 % had 750 -- and the alignment costs at most 8 s_nop per 24 samples."""
+    obj = os.path.join(ROOT, "voice_synth_amd", "csrc", "vs_kernels.o")
+    if not os.path.exists(obj):
+        pytest.skip("the library is not built")
+    import isa_align
+    for arith in (0, 1):
+        for pre1 in (0, 1):
+            for roles in (2, 3):
+                sym = "_Z18vs_synth_ws_kernelILi%dELb%dELi%dEEv12VsKernelArgs" % (arith, pre1, roles)
+                n, on, off, nops = isa_align.superstep_alignment(obj, sym)
+                assert off <= 160, (sym, n, on, off)
+                assert nops <= (8 if arith == 0 else 20), (sym, n, nops)   # (the compiler's own hazard s_nops in the fma loop: 14)

@@ -57,6 +57,30 @@ def loops(elf, sym, min_bytes):
     return res
 
 
+def superstep_alignment(path, sym):
+    """(instructions, 8-byte instructions on an 8-byte boundary, 8-byte instructions off it, s_nop) of the filter's
+    super-step loop of kernel `sym` (exact mangled name): the smallest loop that holds 24 samples' worth of fp64 arithmetic"""
+    elf = device_elf(path)
+    dis = subprocess.run([LLVM + "/llvm-objdump", "-d", elf, "--disassemble-symbols=" + sym], capture_output=True, text=True).stdout
+    ins = []
+    for l in dis.split("\n"):
+        m = re.match(r"\s+(\S.*?)\s+//\s+([0-9A-F]+):\s+([0-9A-F ]+)", l)
+        if m:
+            ins.append((int(m.group(2), 16), m.group(1).split()[0], 4 * len(m.group(3).split())))
+    best = None
+    for _, head, size in loops(elf, sym, 4000):
+        body = [x for x in ins if head <= x[0] < head + size]
+        f64 = sum(1 for _, op, _ in body if op in ("v_mul_f64", "v_add_f64", "v_fma_f64", "v_fmac_f64_e32"))
+        if f64 >= 24 * 22 and (best is None or size < best[0]):
+            best = (size, body)
+    if best is None:
+        raise RuntimeError("no super-step loop found in " + sym)
+    body = best[1]
+    on = sum(1 for a, _, n in body if n == 8 and a % 8 == 0)
+    off = sum(1 for a, _, n in body if n == 8 and a % 8)
+    return len(body), on, off, sum(1 for _, op, _ in body if op == "s_nop")
+
+
 def main():
     path = sys.argv[1]
     sym = sys.argv[2] if len(sys.argv) > 2 else "vs_synth_ws_kernel"

@@ -6,6 +6,20 @@
 #ifndef VS_DEV_FILTER_H
 #define VS_DEV_FILTER_H
 
+/* the lane's 22 taps as vs_superstep wants them: A[1..22] for VS_ARITH_EXACT, -A[1..22] for VS_ARITH_FMA */
+template <int ARITH>
+__device__ __forceinline__ void vs_load_taps(const VsDevLane *__restrict__ L, double (&a)[VS_ORDER + 1])
+{
+  a[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j <= VS_ORDER; ++j) {
+    a[j] = (ARITH == VS_ARITH_FMA) ? -L->a[j - 1] : L->a[j - 1];
+    /* the sign goes INTO the register: left to itself the compiler keeps +A and folds the negation back into every
+     * multiply-add as a source modifier -- free, but only the 8-byte encoding has modifiers */
+    if (ARITH == VS_ARITH_FMA) asm volatile("" : "+v"(a[j]));
+  }
+}
+
 /* the 8 samples of one granule / of 16 bytes of a PCM row, as integers */
 __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
 {
@@ -157,14 +171,18 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
          * instruction every ~5.3 ticks and a dependent one every ~8.4, so two alternating chains
          * never wait), the newest tap (j = 1) last: it is the only one on the sample-to-sample
          * critical path */
-        double p0 = acc, p1 = -(a[2] * y[(t + VS_SS - 2) % VS_SS]);
+        /* VS_ARITH_FMA: a[] holds the NEGATED coefficients (vs_load_taps): p - A*y is fma(-A, y, p), and with the
+         * sign in the register the multiply-add accumulates in place -- V_FMAC_F64, a 4-byte instruction, where the
+         * negating form needs the 8-byte VOP3 encoding: half the loop's code bytes, and nothing that can straddle an
+         * 8-byte boundary (see the chunk alignment above) */
+        double p0 = acc, p1 = a[2] * y[(t + VS_SS - 2) % VS_SS];
 #pragma unroll
         for (int j = 3; j <= VS_ORDER; ++j) {
           const double yj = y[(t + VS_SS - j) % VS_SS];
-          if (j & 1) p0 = __builtin_fma(-a[j], yj, p0);
-          else p1 = __builtin_fma(-a[j], yj, p1);
+          if (j & 1) p0 = __builtin_fma(a[j], yj, p0);
+          else p1 = __builtin_fma(a[j], yj, p1);
         }
-        acc = __builtin_fma(-a[1], y1, p0 + p1);
+        acc = __builtin_fma(a[1], y1, p0 + p1);
       }
       /* y[i] = round2int(y_double[0] - pre_emphasis*y_double[1]), vowel_new.c:284.  PRE1: every
        * lane has pre_emphasis == 1.0 (the reference's default), and 1.0*y is y exactly */
