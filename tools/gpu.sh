@@ -47,7 +47,7 @@ run_step() {
       find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1 | xargs -r head -8 ;;
     pmc)
       local tag="$1"; shift
-      ( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/pmc_$tag" -o "$tag" --output-format csv -- python3 "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/gpurun_out/pmc_$tag.json" 2> "$OLDPWD/gpurun_out/pmc_$tag.err" ) || { tail -5 gpurun_out/pmc_$tag.err; return 1; } ;;
+      ( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --pmc "$@" -d "$OLDPWD/gpurun_out/pmc_$tag" -o "$tag" --output-format csv -- python3 "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$OLDPWD/gpurun_out/pmc_$tag.json" 2> "$OLDPWD/gpurun_out/pmc_$tag.err" ) || { tail -5 gpurun_out/pmc_$tag.err; return 1; } ;;
     smoke)
       timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
       local rc=$?; tail -3 gpurun_out/smoke.log; return $rc ;;
@@ -56,15 +56,15 @@ run_step() {
       #   tools/gpu.sh traffic <key> <kernel substring> [bench.py args...]      VS_LIB selects a variant library
       local key="$1" kern="$2"; shift 2
       for C in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d "$OLDPWD/gpurun_out/pmc_$C" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1 ) || { tail -5 gpurun_out/pmc_$C.log; return 1; }
+        ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $C --output-format csv -d "$OLDPWD/gpurun_out/pmc_$C" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --no-other-configs --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1 ) || { tail -5 gpurun_out/pmc_$C.log; return 1; }
       done
       python tools/summarize_pmc.py traffic gpurun_out/pmc_FETCH_SIZE/bench_counter_collection.csv gpurun_out/pmc_WRITE_SIZE/bench_counter_collection.csv "$key" "$kern" || return 1
       cp profiles/pmc_traffic.json gpurun_out/ ;;   # only gpurun_out/ travels back: copy it into profiles/ by hand
     sq)
       # SQ counters per launch (two passes), then profiles/pmc_valu.json:  tools/gpu.sh sq <key> <kernel substring> [bench.py args...]
       local key="$1" kern="$2"; shift 2
-      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq1" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq1.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq1.log; return 1; }
-      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq2" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq2.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq2.log; return 1; }
+      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq1" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --no-other-configs --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq1.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq1.log; return 1; }
+      ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d "$OLDPWD/gpurun_out/pmc_sq2" -o bench -- python3 "$OLDPWD/bench.py" --no-cpu-baseline --no-other-configs --steps 5 --warmup 2 "$@" > "$OLDPWD/gpurun_out/pmc_sq2.log" 2>&1 ) || { tail -5 gpurun_out/pmc_sq2.log; return 1; }
       python tools/summarize_pmc.py valu gpurun_out/pmc_sq1/bench_counter_collection.csv gpurun_out/pmc_sq2/bench_counter_collection.csv "$key" --kernel "$kern" || return 1
       cp profiles/pmc_valu.json gpurun_out/ ;;
     roles)
@@ -93,7 +93,8 @@ run_step() {
       local tag=${1:-r04}
       run_step test || return 1
       run_step smoke || return 1
-      run_step prof ${tag}_bench --no-cpu-baseline || return 1
+      # (--no-other-configs: configs 4 and 5 launch kernels of the SAME name; the trace's per-kernel average must be config 3's alone)
+      run_step prof ${tag}_bench --no-cpu-baseline --no-other-configs || return 1
       cp "$(find gpurun_out/prof_${tag}_bench -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_kernel_stats.csv
       run_step traffic config3_exact_65536 "vs_synth_ws_kernel<0" || return 1
       run_step traffic config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
