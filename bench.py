@@ -253,9 +253,10 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
     return out
 
 
-def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=5, warm=2):
-    """One BASELINE configuration outside the timed region: plan, `warm` untimed launches, then HIP events on the
-    launch stream around each of `launches` launches, in both arithmetic contracts.  Returns one record per contract:
+def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, warm=5):
+    """One BASELINE configuration outside the timed region: plan, `warm` untimed launches (the chip has idled through the
+    plan's host work and comes back on a low clock), then HIP events on the launch stream around each of `launches`
+    launches, in both arithmetic contracts.  Returns one record per contract:
     {workload, kernel, arith, kernel_ms_avg, kernel_ms_min, roofline_frac, ...}."""
     import torch
 
