@@ -5,7 +5,8 @@
  *       voice_synth_amd/csrc/vs_planhost.c voice_synth_amd/csrc/vs_host.c -Iinclude -lm -lpthread
  * What it goes through: the expansion of 20000 lanes of mixed periods on 8 threads, the failure of the LOWEST bad
  * lane whatever the thread that met it, the stable order by (P, T2, flags) -- a permutation, sorted, ties in input
- * order --, the ring policy over every period it can be asked for, cos rows, the rounds of a node's gather. */
+ * order --, the mixed-rings table of a batch of many periods (every group once, every ring deep, every workgroup inside
+ * the LDS), the ring policy over every period it can be asked for, cos rows, the rounds of a node's gather. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -76,6 +77,57 @@ int main(void)
     }
   }
   free(seen);
+  /* mixed rings over the sorted records (313 groups, the last one ragged): every group exactly once, every ring deep
+   * enough for ITS periods and a multiple of the super-step, every workgroup inside the LDS, regions back to back;
+   * batches of 1 .. 9 groups; a floor no workgroup can afford is refused and leaves nothing behind */
+  for (int pass = 0; pass < 12; pass++) {
+    const size_t m = pass == 0 ? n : (pass == 1 ? 64 : (pass == 2 ? 65 : (size_t)(64 * pass - 17)));
+    const int floor_slots = (pass & 1) ? 144 : 192;
+    VsGroupSlot *gm = NULL;
+    size_t n_wg = 0, lds = 0;
+    int c_min = 0, c_max = 0;
+    const int rc = vs_mixed_rings_build(sorted, m, floor_slots, &gm, &n_wg, &lds, &c_min, &c_max);
+    CHECK(rc == VS_OK);
+    if (rc != VS_OK) continue;
+    const size_t n_groups = (m + 63) / 64;
+    CHECK(n_wg == (n_groups + 3) / 4 && lds <= VS_LDS_LIMIT && c_min >= floor_slots && c_max >= c_min);
+    unsigned char *hit = (unsigned char *)calloc(n_groups, 1);
+    for (size_t w = 0; w < n_wg; w++) {
+      size_t off = 0;
+      for (int k = 0; k < 4; k++) {
+        const VsGroupSlot *gs = &gm[w * 4 + k];
+        if (gs->group < 0) continue;
+        CHECK((size_t)gs->group < n_groups && !hit[gs->group]);
+        hit[gs->group] = 1;
+        int tb = 1, need_ltab = 0, seen_t2[64], ns = 0;
+        for (size_t l = (size_t)gs->group * 64; l < m && l < ((size_t)gs->group + 1) * 64; l++) {
+          if (sorted[l].tbound > tb) tb = sorted[l].tbound;
+          int dup = 0;
+          for (int q = 0; q < ns; q++) dup |= seen_t2[q] == sorted[l].T2;
+          if (!dup) {
+            seen_t2[ns++] = sorted[l].T2;
+            need_ltab += (sorted[l].T2 + 7) & ~7;
+          }
+        }
+        CHECK(gs->ring_slots % VS_SS == 0 && gs->ring_slots >= VS_SS + tb + VS_TRASH_ROWS && gs->ring_slots >= floor_slots);
+        CHECK((double)(gs->ring_slots - VS_SS) / (double)tb >= 1.65);
+        CHECK(gs->ltab_entries == need_ltab && (gs->lds_off & 15) == 0 && (size_t)gs->lds_off == off);
+        off += (((size_t)(gs->ring_slots + VS_TRASH_ROWS) * 128 + (size_t)gs->ltab_entries * 8 + VS_SYNC_WORDS_3 * 64 * 4) + 15) & ~(size_t)15;
+      }
+      CHECK(off <= VS_LDS_LIMIT && off <= lds);
+    }
+    for (size_t g = 0; g < n_groups; g++) CHECK(hit[g]);
+    free(hit);
+    free(gm);
+  }
+  {
+    VsGroupSlot *gm = (VsGroupSlot *)0x1;
+    size_t n_wg = 7, lds = 7;
+    int c_min = 7, c_max = 7;
+    CHECK(vs_mixed_rings_build(sorted, n, 1200, &gm, &n_wg, &lds, &c_min, &c_max) == VS_ERR_UNSUPPORTED);
+    CHECK(gm == (VsGroupSlot *)0x1 && n_wg == 7);
+    CHECK(vs_mixed_rings_build(sorted, 0, 192, &gm, &n_wg, &lds, &c_min, &c_max) == VS_ERR_ARG);
+  }
   free(sorted);
   /* sizes around the merge widths */
   for (size_t m = 1; m <= 70; m++) {

@@ -503,89 +503,25 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (wave_specialised && !all_deep && ws_shared_simd && group_lanes == VS_WAVE && tune->ring_slots == 0 &&
         tune->mixed_rings >= 0 && (tune->ws_pairs == 0 || tune->ws_pairs == 4)) {
       /* the shallowest ring: 192 slots if the workgroups can afford it (short periods hand over often -- eight
-       * super-steps of room instead of six are worth 4 % on config 5, tools/sweep5.sh), else 168, else 144 */
+       * super-steps of room instead of six are worth 4 % on config 5, tools/sweep5.sh), else 168, else 144; the table
+       * itself is built without a device in sight (vs_mixed_rings_build, csrc/vs_planhost.c) */
       int floor_slots = tune->mixed_rings > 1 ? ((tune->mixed_rings + VS_SS - 1) / VS_SS) * VS_SS : 192;
-    retry_floor:;
-      const size_t n_groups = grid, n_wg = (n_groups + 3) / 4;
-      int *tb_g = (int *)malloc(n_groups * sizeof(int));
-      uint32_t *order = (uint32_t *)malloc(n_groups * sizeof(uint32_t));
-      gmap = (VsGroupSlot *)calloc(n_wg * 4, sizeof(VsGroupSlot));
-      size_t *used = (size_t *)calloc(n_wg, sizeof(size_t));
-      bool ok = tb_g && order && gmap && used;
-      int *ltab_g = (int *)malloc(n_groups * sizeof(int)); /* every group reserves what ITS cos rows take */
-      ok = ok && ltab_g;
-      int c_min = 0, c_max = 0;
-      if (ok) {
-        for (size_t g = 0; g < n_groups; g++) {
-          int tb = 1, seen[VS_WAVE], nseen = 0, sum = 0;
-          for (size_t l = g * G; l < n_lanes && l < (g + 1) * G; l++) {
-            if ((int)dl[l].tbound > tb) tb = (int)dl[l].tbound;
-            bool dup = false;
-            for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
-            if (!dup) {
-              seen[nseen++] = dl[l].T2;
-              sum += (dl[l].T2 + 7) & ~7;
-            }
-          }
-          tb_g[g] = tb;
-          ltab_g[g] = sum; /* multiples of 8 doubles */
-          order[g] = (uint32_t)g;
+      for (;;) {
+        int c_min = 0, c_max = 0;
+        const int mrc = vs_mixed_rings_build(dl, n_lanes, floor_slots, &gmap, &n_wg_mixed, &mixed_lds, &c_min, &c_max);
+        if (mrc == VS_ERR_NOMEM) {
+          rc = mrc;
+          goto done;
         }
-        /* groups by longest period, descending (the records are sorted by period already: a stable insertion over
-         * a nearly reversed sequence would be quadratic -- the groups' order IS ascending, so walk it backwards,
-         * and only fix what the cut into groups of 64 may have disturbed) */
-        for (size_t g = 0; g < n_groups; g++) order[g] = (uint32_t)(n_groups - 1 - g);
-        for (size_t i = 1; i < n_groups; i++) {
-          const uint32_t v = order[i];
-          size_t k = i;
-          while (k > 0 && tb_g[order[k - 1]] < tb_g[v]) {
-            order[k] = order[k - 1];
-            k--;
-          }
-          order[k] = v;
+        if (mrc == VS_OK) {
+          for (size_t l = 0; l < n_lanes; l++) dl[l].ready_min = 64; /* every ring is deep: the filter waits for all of its lanes */
+          all_deep = true;
+          slots = c_max;
+          mixed_c_min = c_min;
+          break;
         }
-        for (size_t i = 0; i < n_wg * 4; i++) gmap[i].group = -1;
-        for (size_t i = 0; i < n_groups && ok; i++) {
-          const size_t pass = i / n_wg, pos = i % n_wg;
-          const size_t wg = (pass & 1) ? (n_wg - 1 - pos) : pos; /* snake */
-          const int tb = tb_g[order[i]];
-          int c = ((VS_SS + (int)(1.7 * tb) + VS_SS - 1) / VS_SS) * VS_SS;
-          const int need = ((VS_SS + tb + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
-          if (c < floor_slots) c = floor_slots;
-          if (c < need) c = need;
-          if ((double)(c - VS_SS) / (double)tb < 1.65) c += VS_SS;
-          const size_t fixed = (size_t)ltab_g[order[i]] * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int);
-          const size_t bytes = (((size_t)(c + VS_TRASH_ROWS) * G * sizeof(int16_t) + fixed) + 15) & ~(size_t)15;
-          VsGroupSlot *gs = &gmap[wg * 4 + pass];
-          gs->group = (int32_t)order[i];
-          gs->ring_slots = c;
-          gs->ltab_entries = ltab_g[order[i]];
-          gs->lds_off = (int32_t)used[wg];
-          used[wg] += bytes;
-          if (used[wg] > VS_LDS_LIMIT) ok = false;
-          if (c_min == 0 || c < c_min) c_min = c;
-          if (c > c_max) c_max = c;
-        }
-      }
-      if (ok) {
-        for (size_t w = 0; w < n_wg; w++)
-          if (used[w] > mixed_lds) mixed_lds = used[w];
-        for (size_t l = 0; l < n_lanes; l++) dl[l].ready_min = 64; /* every ring is deep: the filter waits for all of its lanes */
-        all_deep = true;
-        slots = c_max;
-        mixed_c_min = c_min;
-        n_wg_mixed = n_wg;
-      } else {
-        free(gmap);
-        gmap = NULL;
-      }
-      free(tb_g);
-      free(ltab_g);
-      free(order);
-      free(used);
-      if (!gmap && tune->mixed_rings <= 1 && floor_slots > 144) {
+        if (tune->mixed_rings > 1 || floor_slots <= 144) break; /* does not fit: uniform rings, as before */
         floor_slots -= VS_SS;
-        goto retry_floor;
       }
     }
     ready_min = tune->ready_min > 0 ? tune->ready_min : 0; /* 0: the groups' own thresholds */

@@ -298,3 +298,113 @@ int vs_sort_lanes(VsDevLane **pdl, size_t n)
   return VS_OK;
 }
 
+/* mixed rings: group indices by longest period, descending (ties: lower index first).  A merge sort on the index
+ * array -- the groups arrive nearly sorted, but "nearly" is not a bound (jitter on half of the lanes interleaves two
+ * period scales), and a batch of millions of lanes has tens of thousands of groups */
+static void vs_sort_groups_by_period(uint32_t *order, const int *tb, size_t n)
+{
+  uint32_t *tmp = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+  if (!tmp) { /* no memory for the scratch array: an insertion sort gives the same order, slowly */
+    for (size_t i = 1; i < n; i++) {
+      const uint32_t v = order[i];
+      size_t k = i;
+      while (k > 0 && (tb[order[k - 1]] < tb[v] || (tb[order[k - 1]] == tb[v] && order[k - 1] > v))) {
+        order[k] = order[k - 1];
+        k--;
+      }
+      order[k] = v;
+    }
+    return;
+  }
+  uint32_t *src = order, *dst = tmp;
+  for (size_t w = 1; w < n; w *= 2) {
+    for (size_t lo = 0; lo < n; lo += 2 * w) {
+      const size_t mid = (lo + w < n) ? lo + w : n, hi = (lo + 2 * w < n) ? lo + 2 * w : n;
+      size_t a = lo, b = mid, o = lo;
+      while (a < mid && b < hi) {
+        const bool b_first = tb[src[b]] > tb[src[a]] || (tb[src[b]] == tb[src[a]] && src[b] < src[a]);
+        dst[o++] = b_first ? src[b++] : src[a++];
+      }
+      while (a < mid) dst[o++] = src[a++];
+      while (b < hi) dst[o++] = src[b++];
+    }
+    uint32_t *sw = src;
+    src = dst;
+    dst = sw;
+  }
+  if (src != order) memcpy(order, src, n * sizeof(uint32_t));
+  free(tmp);
+}
+
+int vs_mixed_rings_build(const VsDevLane *dl, size_t n_lanes, int floor_slots, VsGroupSlot **gmap_out, size_t *n_wg_out,
+                         size_t *max_lds, int *c_min_out, int *c_max_out)
+{
+  if (!dl || !gmap_out || !n_wg_out || !max_lds || !c_min_out || !c_max_out || n_lanes == 0) return VS_ERR_ARG;
+  const size_t G = VS_WAVE;
+  const size_t n_groups = (n_lanes + G - 1) / G, n_wg = (n_groups + 3) / 4;
+  int *tb_g = (int *)malloc(n_groups * sizeof(int));
+  int *ltab_g = (int *)malloc(n_groups * sizeof(int)); /* every group reserves what ITS cos rows take */
+  uint32_t *order = (uint32_t *)malloc(n_groups * sizeof(uint32_t));
+  VsGroupSlot *gmap = (VsGroupSlot *)calloc(n_wg * 4, sizeof(VsGroupSlot));
+  size_t *used = (size_t *)calloc(n_wg, sizeof(size_t));
+  int rc = (tb_g && ltab_g && order && gmap && used) ? VS_OK : VS_ERR_NOMEM;
+  int c_min = 0, c_max = 0;
+  size_t lds = 0;
+  if (rc == VS_OK) {
+    for (size_t g = 0; g < n_groups; g++) {
+      int tb = 1, seen[VS_WAVE], nseen = 0, sum = 0;
+      for (size_t l = g * G; l < n_lanes && l < (g + 1) * G; l++) {
+        if ((int)dl[l].tbound > tb) tb = (int)dl[l].tbound;
+        bool dup = false;
+        for (int k = 0; k < nseen; k++) dup = dup || (seen[k] == dl[l].T2);
+        if (!dup) {
+          seen[nseen++] = dl[l].T2;
+          sum += (dl[l].T2 + 7) & ~7; /* rows are padded to a multiple of 8 doubles (vs_stage_cos_rows) */
+        }
+      }
+      tb_g[g] = tb;
+      ltab_g[g] = sum;
+      order[g] = (uint32_t)g;
+    }
+    /* groups by longest period, descending; ties by index, so that the table does not depend on the sort */
+    vs_sort_groups_by_period(order, tb_g, n_groups);
+    for (size_t i = 0; i < n_wg * 4; i++) gmap[i].group = -1;
+    for (size_t i = 0; i < n_groups && rc == VS_OK; i++) {
+      const size_t pass = i / n_wg, pos = i % n_wg;
+      const size_t wg = (pass & 1) ? (n_wg - 1 - pos) : pos; /* snake: the longest periods meet the shortest */
+      const int tb = tb_g[order[i]];
+      int c = ((VS_SS + (int)(1.7 * tb) + VS_SS - 1) / VS_SS) * VS_SS;
+      const int need = ((VS_SS + tb + VS_TRASH_ROWS + VS_SS - 1) / VS_SS) * VS_SS;
+      if (c < floor_slots) c = floor_slots;
+      if (c < need) c = need;
+      if ((double)(c - VS_SS) / (double)tb < 1.65) c += VS_SS; /* "deep": the filter may wait for all of its lanes */
+      const size_t fixed = (size_t)ltab_g[order[i]] * sizeof(double) + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int);
+      const size_t bytes = (((size_t)(c + VS_TRASH_ROWS) * G * sizeof(int16_t) + fixed) + 15) & ~(size_t)15;
+      VsGroupSlot *gs = &gmap[wg * 4 + pass];
+      gs->group = (int32_t)order[i];
+      gs->ring_slots = c;
+      gs->ltab_entries = ltab_g[order[i]];
+      gs->lds_off = (int32_t)used[wg];
+      used[wg] += bytes;
+      if (used[wg] > VS_LDS_LIMIT) rc = VS_ERR_UNSUPPORTED;
+      if (c_min == 0 || c < c_min) c_min = c;
+      if (c > c_max) c_max = c;
+    }
+    for (size_t w = 0; w < n_wg; w++)
+      if (used[w] > lds) lds = used[w];
+  }
+  free(tb_g);
+  free(ltab_g);
+  free(order);
+  free(used);
+  if (rc != VS_OK) {
+    free(gmap);
+    return rc;
+  }
+  *gmap_out = gmap;
+  *n_wg_out = n_wg;
+  *max_lds = lds;
+  *c_min_out = c_min;
+  *c_max_out = c_max;
+  return VS_OK;
+}

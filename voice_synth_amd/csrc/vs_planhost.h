@@ -29,6 +29,14 @@ int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min);
 int vs_ring_slots_for(int tmax, int *slots);
 /* stable order by (P, T2, flags); *pdl is replaced by the sorted array */
 int vs_sort_lanes(VsDevLane **pdl, size_t n);
+/* Mixed rings (vs_device.h, VsGroupSlot): the table of a full grid whose 64-utterance groups (lanes [64 g, 64 g + 64) of
+ * the sorted records) differ in period -- every group with the ring depth ITS periods need (1.7 cycles, at least
+ * floor_slots) and its own cos-row reservation, the groups dealt to workgroups of four in snake order of their longest
+ * period.  VS_OK: *gmap (malloc'ed, [*n_wg][4], caller frees) with every group exactly once, the rest -1; *max_lds = the
+ * largest workgroup's LDS bytes (<= VS_LDS_LIMIT), *c_min / *c_max the shallowest / deepest ring.  VS_ERR_UNSUPPORTED:
+ * some workgroup would not fit (nothing allocated).  VS_ERR_NOMEM. */
+int vs_mixed_rings_build(const VsDevLane *dl, size_t n_lanes, int floor_slots, VsGroupSlot **gmap, size_t *n_wg,
+                         size_t *max_lds, int *c_min, int *c_max);
 #ifdef __cplusplus
 }
 #endif
