@@ -4,8 +4,8 @@
  *   gcc -fsanitize=address,undefined -fno-sanitize-recover=all -ffp-contract=off tests/c/test_planhost_asan.c \
  *       voice_synth_amd/csrc/vs_planhost.c voice_synth_amd/csrc/vs_host.c -Iinclude -lm -lpthread
  * What it goes through: the expansion of 20000 lanes of mixed periods on 8 threads, the failure of the LOWEST bad
- * lane whatever the thread that met it, the stable order by (P, T2, flags) -- a permutation, sorted, ties in input
- * order --, the mixed-rings table of a batch of many periods (every group once, every ring deep, every workgroup inside
+ * lane whatever the thread (and the order) that met it, the kernel order by (P, T2, options) found from the lanes and
+ * written straight into place -- a permutation, sorted, ties in input order --, the mixed-rings table of a batch of many periods (every group once, every ring deep, every workgroup inside
  * the LDS), the ring policy over every period it can be asked for, cos rows, the rounds of a node's gather. */
 #include <math.h>
 #include <stdio.h>
@@ -55,11 +55,39 @@ int main(void)
   }
   CHECK(vs_expand_all(lanes, dl, n, 0) == VS_OK);
   for (size_t l = 0; l < n; l++) CHECK(dl[l].row == (int32_t)l && dl[l].P == (int)((float)lanes[l].fs / lanes[l].F0));
+  {
+    /* the batch's statistics, gathered by the threads that make the records, against a walk over the records */
+    VsBatchStats st, st2;
+    lanes[11].pre_emphasis = 0.5f;
+    lanes[12].out_snr = 100.0f;
+    CHECK(vs_expand_all_stats(lanes, dl, n, 0, &st) == VS_OK);
+    int max_T2 = 0, tmax = 1, minlf = 0, pre1 = 1;
+    size_t noisy = 0;
+    for (size_t l = 0; l < n; l++) {
+      if (dl[l].T2 > max_T2) max_T2 = dl[l].T2;
+      if (dl[l].tbound > tmax) tmax = dl[l].tbound;
+      if (dl[l].Lframe > 0 && (minlf == 0 || dl[l].Lframe < minlf)) minlf = dl[l].Lframe;
+      if (dl[l].pre != 1.0) pre1 = 0;
+      if (dl[l].flags & VS_DF_NOISE) noisy++;
+    }
+    CHECK(st.max_T2 == max_T2 && st.tmax == tmax && st.min_lframe == minlf && st.pre1 == pre1 && pre1 == 0);
+    CHECK(st.n_noisy == noisy && st.any_onoise == 1 && st.wide == 0);
+    VsDevLane *tmp = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+    CHECK(vs_expand_all_ordered(lanes, tmp, n, NULL, &st2) == VS_OK);
+    CHECK(memcmp(&st, &st2, sizeof(st)) == 0);       /* the same batch in the kernels' order */
+    free(tmp);
+    lanes[11].pre_emphasis = 1.0f;
+    lanes[12].out_snr = 0.0f;
+    CHECK(vs_expand_all_stats(lanes, dl, n, 0, &st) == VS_OK && st.pre1 == 1 && st.any_onoise == 0);
+  }
 
-  /* the order: a permutation, sorted by (P, T2, flags), ties in input order */
+  /* the order: the records of vs_expand_all_ordered are a permutation of vs_expand_all's, sorted by (P, T2, options),
+   * ties in input order; vs_kernel_order says the same */
   VsDevLane *sorted = (VsDevLane *)malloc(n * sizeof(VsDevLane));
-  memcpy(sorted, dl, n * sizeof(VsDevLane));
-  CHECK(vs_sort_lanes(&sorted, n) == VS_OK);
+  int reordered = 0;
+  CHECK(vs_expand_all_ordered(lanes, sorted, n, &reordered, NULL) == VS_OK && reordered == 1);
+  uint32_t *order = NULL;
+  CHECK(vs_kernel_order(lanes, n, &order) == VS_OK && order != NULL);
   unsigned char *seen = (unsigned char *)calloc(n, 1);
   for (size_t l = 0; l < n; l++) {
     CHECK(sorted[l].row >= 0 && (size_t)sorted[l].row < n);
@@ -67,15 +95,18 @@ int main(void)
       CHECK(!seen[sorted[l].row]);
       seen[sorted[l].row] = 1;
       CHECK(memcmp(&sorted[l], &dl[sorted[l].row], sizeof(VsDevLane)) == 0);
+      CHECK(order && order[l] == (uint32_t)sorted[l].row);
     }
     if (l > 0) {
       const VsDevLane *a = &sorted[l - 1], *b = &sorted[l];
-      const int lt = (a->P != b->P) ? (a->P < b->P) : (a->T2 != b->T2) ? (a->T2 < b->T2) : (a->flags < b->flags);
-      const int eq = a->P == b->P && a->T2 == b->T2 && a->flags == b->flags;
+      const unsigned fa = a->flags & 7u, fb = b->flags & 7u; /* jitter / shimmer / noise on: the option bits of the key */
+      const int lt = (a->P != b->P) ? (a->P < b->P) : (a->T2 != b->T2) ? (a->T2 < b->T2) : (fa < fb);
+      const int eq = a->P == b->P && a->T2 == b->T2 && fa == fb;
       CHECK(lt || eq);
       if (eq) CHECK(a->row < b->row);
     }
   }
+  free(order);
   free(seen);
   /* mixed rings over the sorted records (313 groups, the last one ragged): every group exactly once, every ring deep
    * enough for ITS periods and a multiple of the super-step, every workgroup inside the LDS, regions back to back;
@@ -129,21 +160,35 @@ int main(void)
     CHECK(vs_mixed_rings_build(sorted, 0, 192, &gm, &n_wg, &lds, &c_min, &c_max) == VS_ERR_ARG);
   }
   free(sorted);
-  /* sizes around the merge widths */
+  /* small batches, and a homogeneous one: input order, no index array */
   for (size_t m = 1; m <= 70; m++) {
     VsDevLane *s2 = (VsDevLane *)malloc(m * sizeof(VsDevLane));
-    memcpy(s2, dl + 100, m * sizeof(VsDevLane));
-    CHECK(vs_sort_lanes(&s2, m) == VS_OK);
+    CHECK(vs_expand_all_ordered(lanes + 100, s2, m, NULL, NULL) == VS_OK);
     for (size_t l = 1; l < m; l++) CHECK(s2[l - 1].P <= s2[l].P);
     free(s2);
+  }
+  {
+    vs_lane same[40];
+    VsDevLane out[40];
+    uint32_t *ord = (uint32_t *)0x1;
+    for (int i = 0; i < 40; i++) {
+      same[i] = lanes[7];
+      same[i].seed = 100 + (uint64_t)i;
+    }
+    int re = 1;
+    CHECK(vs_kernel_order(same, 40, &ord) == VS_OK && ord == NULL);
+    CHECK(vs_expand_all_ordered(same, out, 40, &re, NULL) == VS_OK && re == 0);
+    for (int i = 0; i < 40; i++) CHECK(out[i].row == i && out[i].key0 == (uint32_t)(100 + i));
   }
 
   /* two bad lanes met by different threads: the lowest one's error is the answer */
   lanes[17000].F0 = 10.0f;                   /* below 50: VS_ERR_RANGE */
   lanes[3000].cq = 0.0f;                     /* no pulse: VS_ERR_UNSUPPORTED */
   CHECK(vs_expand_all(lanes, dl, n, 0) == VS_ERR_UNSUPPORTED);
+  CHECK(vs_expand_all_ordered(lanes, dl, n, NULL, NULL) == VS_ERR_UNSUPPORTED); /* ... in kernel order too: lane 3000 is the lowest */
   lanes[3000].cq = 0.55f;
   CHECK(vs_expand_all(lanes, dl, n, 0) == VS_ERR_RANGE);
+  CHECK(vs_expand_all_ordered(lanes, dl, n, NULL, NULL) == VS_ERR_RANGE);
   lanes[17000].F0 = 120.0f;
   CHECK(vs_expand_all(lanes, dl, n, 1) == VS_OK);  /* the filter-only records */
 

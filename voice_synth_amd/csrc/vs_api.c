@@ -321,73 +321,56 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   vs_plan *p = NULL;
   if (!dl) return VS_ERR_NOMEM;
   const double t_host0 = vs_now_ms();
-  rc = vs_expand_all(lanes, dl, n_lanes, filter_only);
+  /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its longest lane and
+   * the cos rows of a wavefront are staged once per distinct T2, so a batch with an F0 sweep (BASELINE config 5) is
+   * put in the order of (P, T2, options) before it is cut into groups of 64 -- the records are written straight into
+   * that order (vs_expand_all_ordered).  Placement is internal: each lane still writes its own output row
+   * (VsDevLane.row), and a lane's result does not depend on its neighbours.  Stable, so homogeneous batches keep
+   * their order. */
+  VsBatchStats st; /* gathered by the threads that make the records: no walk over 19 MB of them per question */
+  rc = filter_only ? vs_expand_all_stats(lanes, dl, n_lanes, 1, &st) : vs_expand_all_ordered(lanes, dl, n_lanes, NULL, &st);
   if (rc != VS_OK) goto done;
 
-  int tmax = 1;
-  int min_lframe = 0; /* shortest frame of the batch, once any lane asks for output noise */
-  bool any_onoise = false;
-  {
-    int max_T2 = 0;
-    if (!filter_only)
-      for (size_t l = 0; l < n_lanes; l++)
-        if (dl[l].T2 > max_T2) max_T2 = dl[l].T2;
-    row_of_T2 = (int *)malloc(((size_t)max_T2 + 1) * sizeof(int));
+  /* every lane of a launch with output noise accumulates its frame powers, so the rows of the power table must hold
+   * the lane with the MOST frames (the shortest frame), whether it asks for noise or not */
+  int tmax = st.tmax;
+  int min_lframe = st.min_lframe; /* shortest frame of the batch, once any lane asks for output noise */
+  const bool any_onoise = st.any_onoise != 0;
+  if (!filter_only) {
+    /* one cos row per distinct T2, in the order the records meet them; every record learns where its row starts */
+    row_of_T2 = (int *)malloc(((size_t)st.max_T2 + 1) * sizeof(int));
     if (!row_of_T2) {
       rc = VS_ERR_NOMEM;
       goto done;
     }
-    for (int t = 0; t <= max_T2; t++) row_of_T2[t] = -1;
-  }
-  for (size_t l = 0; l < n_lanes; l++) {
-    /* every lane of a launch with output noise accumulates its frame powers, so the rows of the
-     * power table must hold the lane with the MOST frames, whether it asks for noise or not */
-    if (dl[l].out_snr > 0) any_onoise = true;
-    if (dl[l].Lframe > 0 && (min_lframe == 0 || dl[l].Lframe < min_lframe)) min_lframe = dl[l].Lframe;
-    if (filter_only) continue;
-    const int T2 = dl[l].T2;
-    if (row_of_T2[T2] < 0) {
-      if (costab_len + (size_t)T2 > costab_cap) {
-        size_t cap = costab_cap ? 2 * costab_cap : 1024;
-        while (cap < costab_len + (size_t)T2) cap *= 2;
-        double *grown = (double *)realloc(costab, cap * sizeof(double));
-        if (!grown) {
-          rc = VS_ERR_NOMEM;
-          goto done;
+    for (int t = 0; t <= st.max_T2; t++) row_of_T2[t] = -1;
+    for (size_t l = 0; l < n_lanes; l++) {
+      const int T2 = dl[l].T2;
+      if (row_of_T2[T2] < 0) {
+        if (costab_len + (size_t)T2 > costab_cap) {
+          size_t cap = costab_cap ? 2 * costab_cap : 1024;
+          while (cap < costab_len + (size_t)T2) cap *= 2;
+          double *grown = (double *)realloc(costab, cap * sizeof(double));
+          if (!grown) {
+            rc = VS_ERR_NOMEM;
+            goto done;
+          }
+          costab = grown;
+          costab_cap = cap;
         }
-        costab = grown;
-        costab_cap = cap;
+        vs_cos_row(T2, &costab[costab_len]);
+        row_of_T2[T2] = (int)costab_len;
+        costab_len += (size_t)T2;
       }
-      vs_cos_row(T2, &costab[costab_len]);
-      row_of_T2[T2] = (int)costab_len;
-      costab_len += (size_t)T2;
+      dl[l].tab_off = row_of_T2[T2];
     }
-    dl[l].tab_off = row_of_T2[T2];
-    if (dl[l].tbound > tmax) tmax = dl[l].tbound;
   }
-  bool pre1 = true;
-  for (size_t l = 0; l < n_lanes; l++) pre1 = pre1 && (dl[l].pre == 1.0);
-  bool wide = false;
-  for (size_t l = 0; l < n_lanes && !wide; l++) wide = vs_lane_is_wide(&lanes[l]);
+  const bool pre1 = st.pre1 != 0;
+  const bool wide = st.wide != 0;
   if (!any_onoise) min_lframe = 0;
   if (any_onoise && min_lframe <= 0) {
     rc = VS_ERR_UNSUPPORTED;
     goto done;
-  }
-  /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its
-   * longest lane and the cos rows of a wavefront are staged once per distinct T2, so a batch with
-   * an F0 sweep (BASELINE config 5) is sorted by (P, T2, options) before it is cut into groups of
-   * 64.  Placement is internal: each lane still writes its own output row (VsDevLane.row), and a
-   * lane's result does not depend on its neighbours.  Stable sort, so homogeneous batches keep
-   * their order. */
-  if (!filter_only) {
-    bool mixed = false;
-    for (size_t l = 1; l < n_lanes && !mixed; l++)
-      mixed = dl[l].P != dl[0].P || dl[l].T2 != dl[0].T2 || dl[l].flags != dl[0].flags;
-    if (mixed) {
-      rc = vs_sort_lanes(&dl, n_lanes);
-      if (rc != VS_OK) goto done;
-    }
   }
   /* Launch shape.  A full chip is 4 x cu_count SIMDs.  The fused kind runs WAVE-SPECIALISED
    * whenever it can: two or three wavefronts per 64 utterances with one job each, coupled through
@@ -547,8 +530,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * -- open phase | noise | filter -- if the extra progress words and order boxes still fit next
        * to four rings.  Otherwise two: generator | filter. */
       const int bytes3 = (int)((lds_bytes + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
-      size_t noisy = 0;
-      for (size_t l = 0; l < n_lanes; l++) noisy += (dl[l].flags & VS_DF_NOISE) ? 1 : 0;
+      const size_t noisy = st.n_noisy;
       /* only where there is noise to hand over: without it the third wavefront just relays
        * progress words (BASELINE config 2's shape: 3.01 ms against 2.75 with two roles); and only over
        * deep rings: the filter wavefront of the three-role kernel waits for ALL of its lanes, which a

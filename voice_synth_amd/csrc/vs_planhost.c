@@ -196,41 +196,79 @@ int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 
 /* expansion of the lane records: independent per lane, so large batches are cut over a few host
  * threads (65536 lanes: 38 ms on one core, the kernel itself takes under 3 ms) */
+#define VS_EXPAND_THREADS 16
 typedef struct ExpandJob {
   const vs_lane *lanes;
   VsDevLane *dl;
+  const uint32_t *order; /* record i is made from lane order[i] (NULL: from lane i) */
   size_t lo, hi;
   int filter_only;
-  int rc;          /* first failure in [lo, hi) */
-  size_t bad;      /* ... and the lane it belongs to */
+  int rc;          /* the failure of the LOWEST lane met in [lo, hi) */
+  size_t bad;      /* ... and that lane */
+  VsBatchStats st; /* of the records this job made */
 } ExpandJob;
+
+static void stats_init(VsBatchStats *st)
+{
+  memset(st, 0, sizeof(*st));
+  st->tmax = 1;
+  st->pre1 = 1;
+}
+static void stats_lane(VsBatchStats *st, const vs_lane *lane, const VsDevLane *d)
+{
+  if (d->T2 > st->max_T2) st->max_T2 = d->T2;
+  if (d->tbound > st->tmax) st->tmax = d->tbound;
+  if (d->Lframe > 0 && (st->min_lframe == 0 || d->Lframe < st->min_lframe)) st->min_lframe = d->Lframe;
+  if (d->out_snr > 0) st->any_onoise = 1;
+  if (d->pre != 1.0) st->pre1 = 0;
+  if (vs_lane_is_wide(lane)) st->wide = 1;
+  if (d->flags & VS_DF_NOISE) st->n_noisy++;
+}
+static void stats_merge(VsBatchStats *a, const VsBatchStats *b)
+{
+  if (b->max_T2 > a->max_T2) a->max_T2 = b->max_T2;
+  if (b->tmax > a->tmax) a->tmax = b->tmax;
+  if (b->min_lframe > 0 && (a->min_lframe == 0 || b->min_lframe < a->min_lframe)) a->min_lframe = b->min_lframe;
+  a->any_onoise |= b->any_onoise;
+  a->pre1 &= b->pre1;
+  a->wide |= b->wide;
+  a->n_noisy += b->n_noisy;
+}
 
 static void *expand_range(void *arg)
 {
   ExpandJob *j = (ExpandJob *)arg;
   j->rc = VS_OK;
-  for (size_t l = j->lo; l < j->hi; l++) {
-    const int rc = j->filter_only ? vs_expand_filter_lane(&j->lanes[l], (int32_t)l, &j->dl[l])
-                                  : vs_expand_lane(&j->lanes[l], (int32_t)l, &j->dl[l]);
+  j->bad = (size_t)-1;
+  stats_init(&j->st);
+  for (size_t i = j->lo; i < j->hi; i++) {
+    const size_t l = j->order ? (size_t)j->order[i] : i;
+    const int rc = j->filter_only ? vs_expand_filter_lane(&j->lanes[l], (int32_t)l, &j->dl[i])
+                                  : vs_expand_lane(&j->lanes[l], (int32_t)l, &j->dl[i]);
     if (rc != VS_OK) {
-      j->rc = rc;
-      j->bad = l;
-      break;
+      if (l < j->bad) {
+        j->rc = rc;
+        j->bad = l;
+      }
+      if (!j->order) break; /* in input order nothing behind it can be lower */
+      continue;
     }
+    stats_lane(&j->st, &j->lanes[l], &j->dl[i]);
   }
   return NULL;
 }
 
-int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only)
+static int expand_with_order(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, const uint32_t *order,
+                             VsBatchStats *stats)
 {
   long nt = 1;
   if (n_lanes >= 8192) {
     nt = sysconf(_SC_NPROCESSORS_ONLN);
-    if (nt > 8) nt = 8;
+    if (nt > VS_EXPAND_THREADS) nt = VS_EXPAND_THREADS;
     if (nt < 1) nt = 1;
   }
-  ExpandJob jobs[8];
-  pthread_t th[8];
+  ExpandJob jobs[VS_EXPAND_THREADS];
+  pthread_t th[VS_EXPAND_THREADS];
   const size_t per = (n_lanes + (size_t)nt - 1) / (size_t)nt;
   int started = 0, n_jobs = 0;
   for (long t = 0; t < nt; t++) {
@@ -238,6 +276,7 @@ int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filte
     if (lo >= hi) break;
     jobs[n_jobs].lanes = lanes;
     jobs[n_jobs].dl = dl;
+    jobs[n_jobs].order = order;
     jobs[n_jobs].lo = lo;
     jobs[n_jobs].hi = hi;
     jobs[n_jobs].filter_only = filter_only;
@@ -252,50 +291,109 @@ int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filte
   }
   for (int t = started; t < n_jobs; t++) expand_range(&jobs[t]);
   for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-  for (int t = 0; t < n_jobs; t++) /* the failure of the lowest lane: the same answer whatever the thread count */
-    if (jobs[t].rc != VS_OK) return jobs[t].rc;
-  return VS_OK;
+  /* the failure of the lowest lane: the same answer whatever the thread count and the order */
+  int rc = VS_OK;
+  size_t bad = (size_t)-1;
+  VsBatchStats all;
+  stats_init(&all);
+  for (int t = 0; t < n_jobs; t++) {
+    if (jobs[t].rc != VS_OK && jobs[t].bad < bad) {
+      rc = jobs[t].rc;
+      bad = jobs[t].bad;
+    }
+    stats_merge(&all, &jobs[t].st);
+  }
+  if (stats) *stats = all;
+  return rc;
 }
 
-/* Wavefronts are formed from lanes with similar periods: stable order by (P, T2, flags).  A merge sort
- * of lane indices (stable by construction), then one pass that moves the records. */
-static int lane_before(const VsDevLane *a, const VsDevLane *b)
+int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only)
 {
-  if (a->P != b->P) return a->P < b->P;
-  if (a->T2 != b->T2) return a->T2 < b->T2;
-  return a->flags < b->flags;
+  return expand_with_order(lanes, dl, n_lanes, filter_only, NULL, NULL);
 }
 
-int vs_sort_lanes(VsDevLane **pdl, size_t n)
+int vs_expand_all_stats(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, VsBatchStats *stats)
 {
-  VsDevLane *dl = *pdl;
-  uint32_t *idx = (uint32_t *)malloc(n * sizeof(uint32_t)), *tmp = (uint32_t *)malloc(n * sizeof(uint32_t));
-  VsDevLane *sorted = (VsDevLane *)malloc(n * sizeof(VsDevLane));
-  if (!idx || !tmp || !sorted) {
-    free(idx);
-    free(tmp);
-    free(sorted);
+  return expand_with_order(lanes, dl, n_lanes, filter_only, NULL, stats);
+}
+
+/* The order the kernels want -- wavefronts are formed from lanes with similar periods: by (P, T2, jitter / shimmer /
+ * noise on or off), stable -- found BEFORE the records are made, from a 64-bit key per lane that restates the three
+ * fields (flowgen_shimmer.c:244, :317 and the option flags), so that the expansion writes every record straight into
+ * its place: no second pass over 19 MB of records (BASELINE config 5: the merge sort + gather of round 4 took longer
+ * than the expansion itself).  LSD radix sort of the lane indices, 16 bits per pass, passes whose digit is the same
+ * in every key skipped (a homogeneous batch: none run, and *order_out stays NULL = input order). */
+static uint64_t lane_order_key(const vs_lane *lane)
+{
+  uint64_t P = 0, T2 = 0;
+  if (lane->fs > 0 && lane->F0 > 0.0f) {
+    const float q = (float)lane->fs / lane->F0; /* P = (int)((float)fs/F0), flowgen_shimmer.c:244 */
+    if (q >= 0.0f && q < 67108864.0f) P = (uint64_t)(int)q;
+  }
+  if (lane->cq >= 0.0f && lane->cq <= 1.0f) {
+    const double t2 = ceil(0.5 * lane->cq * (double)P); /* T2, flowgen_shimmer.c:317 */
+    if (t2 >= 0.0 && t2 < 67108864.0) T2 = (uint64_t)t2;
+  }
+  uint64_t f = 0;
+  if ((lane->flags & VS_FLAG_JITTER) && lane->jitter != 0.0) f |= 1;
+  if ((lane->flags & VS_FLAG_SHIMMER) && lane->shimmer != 0.0) f |= 2;
+  if (lane->flags & VS_FLAG_NOISE) f |= 4;
+  return (P << 36) | (T2 << 8) | f;
+}
+
+int vs_kernel_order(const vs_lane *lanes, size_t n_lanes, uint32_t **order_out)
+{
+  *order_out = NULL;
+  if (n_lanes < 2 || n_lanes > 0xFFFFFFFFu) return VS_OK;
+  uint64_t *key = (uint64_t *)malloc(n_lanes * sizeof(uint64_t));
+  if (!key) return VS_ERR_NOMEM;
+  uint64_t all_or = 0, all_and = ~(uint64_t)0;
+  for (size_t l = 0; l < n_lanes; l++) {
+    key[l] = lane_order_key(&lanes[l]);
+    all_or |= key[l];
+    all_and &= key[l];
+  }
+  const uint64_t varying = all_or ^ all_and; /* bits that differ somewhere */
+  if (!varying) {
+    free(key);
+    return VS_OK;
+  }
+  uint32_t *a = (uint32_t *)malloc(n_lanes * sizeof(uint32_t)), *b = (uint32_t *)malloc(n_lanes * sizeof(uint32_t));
+  size_t *count = (size_t *)malloc(65537 * sizeof(size_t));
+  if (!a || !b || !count) {
+    free(key);
+    free(a);
+    free(b);
+    free(count);
     return VS_ERR_NOMEM;
   }
-  for (size_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
-  for (size_t w = 1; w < n; w *= 2) {
-    for (size_t lo = 0; lo < n; lo += 2 * w) {
-      const size_t mid = (lo + w < n) ? lo + w : n, hi = (lo + 2 * w < n) ? lo + 2 * w : n;
-      size_t a = lo, b = mid, o = lo;
-      while (a < mid && b < hi) tmp[o++] = lane_before(&dl[idx[b]], &dl[idx[a]]) ? idx[b++] : idx[a++]; /* ties: the left run first */
-      while (a < mid) tmp[o++] = idx[a++];
-      while (b < hi) tmp[o++] = idx[b++];
-    }
-    uint32_t *sw = idx;
-    idx = tmp;
-    tmp = sw;
+  for (size_t l = 0; l < n_lanes; l++) a[l] = (uint32_t)l;
+  for (int shift = 0; shift < 64; shift += 16) {
+    if (!((varying >> shift) & 0xFFFFu)) continue;
+    memset(count, 0, 65537 * sizeof(size_t));
+    for (size_t i = 0; i < n_lanes; i++) count[((key[a[i]] >> shift) & 0xFFFFu) + 1]++;
+    for (size_t d = 0; d < 65536; d++) count[d + 1] += count[d];
+    for (size_t i = 0; i < n_lanes; i++) b[count[(key[a[i]] >> shift) & 0xFFFFu]++] = a[i];
+    uint32_t *sw = a;
+    a = b;
+    b = sw;
   }
-  for (size_t i = 0; i < n; i++) sorted[i] = dl[idx[i]];
-  free(idx);
-  free(tmp);
-  free(dl);
-  *pdl = sorted;
+  free(key);
+  free(b);
+  free(count);
+  *order_out = a;
   return VS_OK;
+}
+
+int vs_expand_all_ordered(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int *reordered, VsBatchStats *stats)
+{
+  uint32_t *order = NULL;
+  int rc = vs_kernel_order(lanes, n_lanes, &order);
+  if (rc != VS_OK) return rc;
+  if (reordered) *reordered = order != NULL;
+  rc = expand_with_order(lanes, dl, n_lanes, 0, order, stats);
+  free(order);
+  return rc;
 }
 
 /* mixed rings: group indices by longest period, descending (ties: lower index first).  A merge sort on the index

@@ -20,15 +20,30 @@ bool vs_lane_is_wide(const vs_lane *lane);
 /* one lane -> the record the kernels read (validated); the filter-only form fills what vowel reads */
 int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
 int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
-/* all lanes, cut over up to 8 host threads for batches >= 8192; the failure of the lowest lane wins */
+/* what a plan needs to know about its batch as a whole: gathered by the threads that make the records, so that the
+ * plan does not walk 19 MB of them again for every question */
+typedef struct VsBatchStats {
+  int max_T2;       /* longest cos row */
+  int tmax;         /* longest period any lane's rejection test admits (VsDevLane.tbound) */
+  int min_lframe;   /* shortest frame (> 0) of the batch, 0: none */
+  int any_onoise;   /* some lane asks for vowel -n */
+  int pre1;         /* every lane has pre_emphasis == 1.0 */
+  int wide;         /* some lane carries a coefficient set of 23..40 taps */
+  size_t n_noisy;   /* lanes with glottal noise (VS_DF_NOISE) */
+} VsBatchStats;
+/* all lanes, cut over up to 16 host threads for batches >= 8192; the failure of the lowest lane wins; stats may be NULL */
 int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only);
+int vs_expand_all_stats(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, VsBatchStats *stats);
+/* the source records in the order the kernels want -- stable by (P, T2, jitter / shimmer / noise on) -- written
+ * straight into place: *order (malloc'ed, caller frees; NULL = input order: a homogeneous batch) says which lane
+ * record i comes from (vs_kernel_order), vs_expand_all_ordered does both */
+int vs_kernel_order(const vs_lane *lanes, size_t n_lanes, uint32_t **order);
+int vs_expand_all_ordered(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int *reordered, VsBatchStats *stats);
 void vs_cos_row(int T2, double *row);
 /* ring capacity (slots per utterance) and super-step threshold for periods up to tmax */
 int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request, double depth);
 int vs_ring_policy(int tmax, int cap, int *slots, int *ready_min);
 int vs_ring_slots_for(int tmax, int *slots);
-/* stable order by (P, T2, flags); *pdl is replaced by the sorted array */
-int vs_sort_lanes(VsDevLane **pdl, size_t n);
 /* Mixed rings (vs_device.h, VsGroupSlot): the table of a full grid whose 64-utterance groups (lanes [64 g, 64 g + 64) of
  * the sorted records) differ in period -- every group with the ring depth ITS periods need (1.7 cycles, at least
  * floor_slots) and its own cos-row reservation, the groups dealt to workgroups of four in snake order of their longest
