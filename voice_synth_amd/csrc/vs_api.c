@@ -133,6 +133,7 @@ void vs_ctx_destroy(vs_ctx *ctx)
 {
   if (!ctx) return;
   vs_pool_release(ctx);
+  free(ctx->plan_scratch);
   free(ctx);
 }
 
@@ -311,8 +312,16 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   }
   const vs_tuning *tune = &ctx->tuning;
   int rc = VS_OK;
-  /* host memory of this call, released at `done` */
-  VsDevLane *dl = (VsDevLane *)malloc(n_lanes * sizeof(VsDevLane));
+  /* the records are made in host memory the context keeps between plans (grown on demand, released by
+   * vs_ctx_destroy: a fresh 19 MB block per plan is thousands of page faults); everything else of this call is
+   * released at `done` */
+  if (ctx->plan_scratch_bytes < n_lanes * sizeof(VsDevLane)) {
+    free(ctx->plan_scratch);
+    ctx->plan_scratch_bytes = 0;
+    ctx->plan_scratch = malloc(n_lanes * sizeof(VsDevLane));
+    if (ctx->plan_scratch) ctx->plan_scratch_bytes = n_lanes * sizeof(VsDevLane);
+  }
+  VsDevLane *dl = (VsDevLane *)ctx->plan_scratch;
   double *costab = NULL;   /* the cos rows, one per distinct T2 */
   size_t costab_len = 0, costab_cap = 0;
   int *row_of_T2 = NULL;   /* first entry of the row of T2 in costab, -1: not built yet */
@@ -680,7 +689,6 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   *out = p;
   rc = VS_OK;
 done:
-  free(dl);
   free(costab);
   free(row_of_T2);
   free(awide);
