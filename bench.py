@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   sustained    : the same plan launched back to back for >= 2 s (outside the timed region), HIP events on the
                  first and the last launch: the figure a compute-bound kernel holds once the chip has settled
                  on its clock, next to the 20-step burst above (`ratio_to_timed_region`);
+  fresh_batches: N = 1 only -- a plan per batch of NEW utterances (new seeds) + its launch, the next plan made on the host
+                 while this batch's kernel runs: what the product path around the kernel costs a caller who does not
+                 launch the same plan twice;
   other_arith  : the other arithmetic contract (fma when the run is exact), HIP events around each of
                  10 launches after 3 warm-ups, outside the timed region;
   config4      : N > 1 only -- BASELINE.json's configuration for the node: 262144 utterances x 44100
@@ -251,6 +254,60 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         out["gpu_rms_error_lsb"] = rms
         out["gpu_rms_error_normalised"] = rms / 32768.0
     return out
+
+
+def fresh_batches(eng, dev, stream, lanes, n_samples, out, pitch, per_gpu, batches=12):
+    """`batches` batches of NEW utterances (the timed workload with other seeds): vs_plan_create + launch per batch, the
+    next batch's plan made on the host while this batch's kernel runs; wall clock over all of them, HIP events around it."""
+    import numpy as np
+    import torch
+
+    import voice_synth_amd as vs
+
+    # the batches' utterance descriptions are the CALLER's input and exist before the clock starts: `batches` + 2 copies
+    # of the lane array, each with seeds nobody has synthesised yet (27 MB each)
+    descr = []
+    for b in range(batches + 2):
+        mine = (vs.Lane * per_gpu).from_buffer_copy(lanes)
+        view = np.frombuffer(mine, dtype=np.dtype(vs.Lane))
+        view["seed"] += np.uint64((b + 1) * per_gpu)
+        view["out_seed"] += np.uint64((b + 1) * per_gpu)
+        descr.append(mine)
+    plans, host_ms, upload_ms = [], [], []
+
+    def make(k):
+        p_ = eng.plan(descr[k], n_samples)
+        h_, u_ = p_.timing()
+        host_ms.append(h_)
+        upload_ms.append(u_)
+        return p_
+
+    for k in range(2):                                               # warm-up: two batches, untimed
+        p_ = make(batches + k)
+        p_.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
+        torch.cuda.synchronize(dev)
+        p_.status()
+        p_.close()
+    del host_ms[:], upload_ms[:]
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    nxt = make(0)
+    for k in range(batches):
+        cur = nxt
+        cur.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)   # enqueues; the kernel runs while ...
+        if k + 1 < batches:
+            nxt = make(k + 1)                                            # ... the next batch's plan is made
+        plans.append(cur)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    for p_ in plans:
+        p_.status()
+        p_.close()
+    host_ms.sort()
+    return {"batches": batches, "utterances_per_batch": per_gpu, "ms_per_batch": round(elapsed / batches * 1e3, 4),
+            "Msamples/s": round(per_gpu * n_samples * batches / elapsed / 1e6, 1),
+            "plan_host_ms_median": round(host_ms[len(host_ms) // 2], 3), "plan_upload_ms_median": round(sorted(upload_ms)[len(upload_ms) // 2], 3),
+            "how": "vs_plan_create (utterances with new seeds, described beforehand) + launch per batch, plan k + 1 made while kernel k runs; wall clock, python in the loop"}
 
 
 def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, warm=5):
@@ -508,6 +565,17 @@ def main():
     other_ms = sum(other_kern) / len(other_kern)
     eng.set_arith(arith)
 
+    # ---- fresh batches, outside the timed region (N = 1 only): what a caller pays who synthesises NEW utterances -- a plan
+    # per batch (new seeds: vs_plan_create on the host threads + upload) and its launch, batch k + 1's plan made while
+    # batch k's kernel runs (a launch only enqueues).  The timed region above launches ONE plan over and over: that is the
+    # kernel; this is the product path around it.
+    fresh = None
+    if world == 1 and rank == 0 and not args.no_other_configs:
+        try:
+            fresh = fresh_batches(eng, dev, stream, lanes, n_samples, out, pitch, per_gpu)
+        except Exception as exc:  # pragma: no cover - reported in the line
+            fresh = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- the other BASELINE configurations, outside the timed region (N = 1 only; at N > 1 the config-4 block below
     # is the second workload): configs 2, 4 (one GPU's shard of the 8-GPU cut) and 5, each launched a few times with
     # HIP events around every launch, in both arithmetic contracts -- so that the driver's line carries every
@@ -607,6 +675,7 @@ def main():
                             "kernel_ms_min": round(other_kern[0], 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
             "other_configs": other_configs,
+            "fresh_batches": fresh,
             "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
                      "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
                              "sort, cos rows; allocation + upload + wait.  Outside every timed region."},

@@ -174,3 +174,8 @@ def test_bench_line_carries_every_baseline_configuration():
         assert "error" not in r and r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] >= r["kernel_ms_min"] > 0
         assert abs(r["roofline_frac"] - 2 * r["utterances"] * r["samples_per_utterance"] / (r["kernel_ms_avg"] * 1e-3) / 8e12) < 2e-4
     assert oc[2]["utterances"] == 32768 and oc[2]["samples_per_utterance"] == 44100
+    # ... and what a caller pays who makes a plan per batch of new utterances (plan k + 1 overlapped with kernel k)
+    fb = d["fresh_batches"]
+    assert "error" not in fb and fb["batches"] >= 10 and fb["utterances_per_batch"] == 65536
+    assert fb["ms_per_batch"] >= 0.9 * d["roofline"]["kernel_ms_min"] and fb["plan_host_ms_median"] > 0
+    assert abs(fb["Msamples/s"] - 65536 * 16000 / (fb["ms_per_batch"] * 1e-3) / 1e6) / fb["Msamples/s"] < 1e-3

@@ -133,6 +133,10 @@ void vs_ctx_destroy(vs_ctx *ctx)
 {
   if (!ctx) return;
   vs_pool_release(ctx);
+  if (ctx->own_upload) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamDestroy(ctx->own_upload);
+  }
   free(ctx->plan_scratch);
   free(ctx);
 }
@@ -659,10 +663,15 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       p->owns_flow = 1;
     }
   }
-  /* the records go up on the context's stream -- or, inside a chunk pipeline, on its upload stream, so
-   * that the wait below is for THESE copies and not for the previous chunk's kernel; the launch that
-   * uses them is enqueued after this function has returned */
-  hipStream_t up = ctx->upload ? ctx->upload : ctx->stream;
+  /* the records go up on a stream of the context's own -- inside a chunk pipeline on the pipeline's upload stream --,
+   * never on the launch stream: the wait below is for THESE copies and not for whatever kernel the caller has running
+   * (the previous chunk's, or batch k's while batch k + 1 is being planned); the launch that uses the records is
+   * enqueued after this function has returned, i.e. after the copies have completed */
+  hipStream_t up = ctx->upload;
+  if (!up && !zero_copy) {
+    if (!ctx->own_upload && e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_upload, hipStreamNonBlocking);
+    up = ctx->own_upload;
+  }
   if (!zero_copy) {
     if (e == hipSuccess && wide)
       e = hipMemcpyAsync(p->d_awide, awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double), hipMemcpyHostToDevice, up);

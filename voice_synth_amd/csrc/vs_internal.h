@@ -44,7 +44,10 @@ struct vs_ctx {
   int device;
   int arith;
   hipStream_t stream;
-  hipStream_t upload;   /* when set (the chunk pipelines): plan records go up on this stream instead of `stream` */
+  hipStream_t upload;   /* when set (the chunk pipelines): plan records go up on this stream */
+  hipStream_t own_upload; /* ... else on this one, created with the first plan that copies: NEVER on `stream`, where the
+                             copy would queue behind whatever kernel the caller has running there -- a caller who makes
+                             batch k + 1's plan while batch k's kernel runs would wait for that kernel in vs_plan_create */
   int last_hip_error;
   char name[128];
   int cu_count;
