@@ -498,10 +498,10 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
      * all-lanes filter loop runs everywhere (VsGroupSlot, vs_device.h). */
     if (wave_specialised && !all_deep && ws_shared_simd && group_lanes == VS_WAVE && tune->ring_slots == 0 &&
         tune->mixed_rings >= 0 && (tune->ws_pairs == 0 || tune->ws_pairs == 4)) {
-      /* the shallowest ring: 192 slots if the workgroups can afford it (short periods hand over often -- eight
-       * super-steps of room instead of six are worth 4 % on config 5, tools/sweep5.sh), else 168, else 144; the table
+      /* the shallowest ring: 216 slots if the workgroups can afford it (short periods hand over often -- nine
+       * super-steps of room instead of six are worth 4 % on config 5, tools/sweep5.sh), else 192, 168, 144; the table
        * itself is built without a device in sight (vs_mixed_rings_build, csrc/vs_planhost.c) */
-      int floor_slots = tune->mixed_rings > 1 ? ((tune->mixed_rings + VS_SS - 1) / VS_SS) * VS_SS : 192;
+      int floor_slots = tune->mixed_rings > 1 ? ((tune->mixed_rings + VS_SS - 1) / VS_SS) * VS_SS : 216;
       for (;;) {
         int c_min = 0, c_max = 0;
         const int mrc = vs_mixed_rings_build(dl, n_lanes, floor_slots, &gmap, &n_wg_mixed, &mixed_lds, &c_min, &c_max);
@@ -856,11 +856,12 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
     if (p->tuning.gen_low <= 0) a.gen_low = 144;
   }
   /* three roles over mixed rings (an F0 sweep): the short-period groups hand over twice as often per sample as
-   * config 3's and their rings are shallow in SAMPLES (192 slots = 8 super-steps): a round starts for three quarters of
-   * the lanes, and at once for a lane that is down to two super-steps (tools/sweep5.sh: 3.36 -> 3.22 ms, same box) */
+   * config 3's and their rings are shallow in SAMPLES (216 slots = 9 super-steps): a round starts for three quarters of
+   * the lanes, and at once for a lane that is down to 56 samples (tools/sweep5.sh: 3.36 -> 3.22 ms with 192 / 48, another
+   * 1 % exact and 3 % fma with 216 / 56, profiles/r05_config5_sweep.txt) */
   if (p->ws_roles == 3 && p->d_group_map) {
     if (p->tuning.gen_min <= 0) a.gen_min = 48;
-    if (p->tuning.gen_low <= 0) a.gen_low = 48;
+    if (p->tuning.gen_low <= 0) a.gen_low = 56;
   }
   a.spin_limit = p->tuning.spin_limit > 0 ? p->tuning.spin_limit : (1 << 22);
   a.fault = p->tuning.fault;
