@@ -100,6 +100,11 @@ int vs_copy_path_warm(vs_ctx *ctx)
     ctx->last_hip_error = (int)e;
     return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
   }
+  /* ... and the stream the records of later plans go up on (creating a stream costs milliseconds the first time) */
+  if (!ctx->own_upload && hipStreamCreateWithFlags(&ctx->own_upload, hipStreamNonBlocking) != hipSuccess) {
+    ctx->own_upload = NULL;
+    (void)hipGetLastError(); /* the plan tries again and reports it */
+  }
   ctx->copy_warm = 1;
   ctx->copy_warm_ms = vs_now_ms() - t0;
   return VS_OK;
