@@ -275,6 +275,14 @@ int vs_ctx_synchronize(vs_ctx *ctx);
  * after it has been delivered, so rows a callback has already seen, or that already lie in the caller's
  * buffer, are to be discarded as well when the call returns VS_ERR_INTERNAL. */
 int vs_plan_status(vs_plan *plan, int *flags);
+/* The same utterances with NEW draws: replaces every lane's seed (and out_seed: out_seeds may be NULL = the same values)
+ * in the plan's device records -- what running the reference's programs again does, which seed from the clock
+ * (flowgen_shimmer.c:241, vowel_new.c:234).  seeds[i] belongs to lanes[i] of vs_plan_create, whatever order the plan
+ * keeps its records in; the arrays are the caller's again when the call returns.  Stream-ordered with the plan's
+ * launches on the context's stream (launches enqueued before see the old seeds, launches after the new ones); 16 bytes
+ * per lane go up instead of a whole new plan (65536 lanes: 0.1 ms against 3 ms).  A lane's seed does not change which
+ * kernel or ring the plan uses. */
+int vs_plan_reseed(vs_plan *plan, const uint64_t *seeds, const uint64_t *out_seeds);
 
 /* Host cost of vs_plan_create(): host_ms = validation, parameter expansion, sorting, cosine
  * tables (cut over up to 8 host threads for batches >= 8192); upload_ms = device allocation,

@@ -179,3 +179,4 @@ def test_bench_line_carries_every_baseline_configuration():
     assert "error" not in fb and fb["batches"] >= 10 and fb["utterances_per_batch"] == 65536
     assert fb["ms_per_batch"] >= 0.9 * d["roofline"]["kernel_ms_min"] and fb["plan_host_ms_median"] > 0
     assert abs(fb["Msamples/s"] - 65536 * 16000 / (fb["ms_per_batch"] * 1e-3) / 1e6) / fb["Msamples/s"] < 1e-3
+    assert 0.9 * d["roofline"]["kernel_ms_min"] <= fb["reseed_ms_per_batch"] <= fb["ms_per_batch"]   # new draws cost less than new plans

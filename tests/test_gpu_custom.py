@@ -267,3 +267,66 @@ def test_small_host_calls_run_without_a_single_copy():
         assert np.array_equal(eng.source(lanes, ns), want_flow)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("index,n", [(3, 700), (5, 70000), (2, 300)])
+def test_plan_reseed_is_a_new_plan_with_those_seeds(index, n):
+    """vs_plan_reseed: the same utterances with new draws (what running the reference again does: it seeds from the clock,
+    flowgen_shimmer.c:241) -- 16 bytes per lane go up instead of a new plan.  The reseeded plan must give, sample for sample,
+    what a plan made from lanes with those seeds gives (config 5 at full-grid size: records in kernel order over mixed rings,
+    seeds[i] still belongs to lane i), launches enqueued BEFORE the reseed keep the old seeds, and a second reseed right
+    behind the first does not disturb it."""
+    specs, fs, dur, _ = configs.config_specs(index, n)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = 3000
+    eng = vs.Engine(0)
+    try:
+        plan = eng.plan(lanes, ns)
+        out0, out1, out2 = (eng.dev_alloc(n * ns * 2) for _ in range(3))
+        rng = np.random.default_rng(index)
+        s1 = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+        s2 = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+        plan.launch(vs.VS_KIND_SYNTH, out0)          # old seeds
+        plan.reseed(s1)
+        plan.launch(vs.VS_KIND_SYNTH, out1)          # s1
+        plan.reseed(s2, out_seeds=s1)
+        plan.launch(vs.VS_KIND_SYNTH, out2)          # s2
+        eng.synchronize()
+        assert plan.status() == 0
+        got = [eng.dev_download(o, (n, ns), np.int16) for o in (out0, out1, out2)]
+        for o in (out0, out1, out2):
+            eng.dev_free(o)
+        plan.close()
+        view = np.frombuffer(lanes, dtype=np.dtype(vs.Lane))
+        want0 = po.synth(lanes, ns)
+        view["seed"] = s1
+        want1 = po.synth(lanes, ns)
+        view["seed"] = s2
+        want2 = po.synth(lanes, ns)
+        assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1) and np.array_equal(got[2], want2)
+        assert not np.array_equal(got[0], got[1])
+    finally:
+        eng.close()
+
+
+def test_plan_reseed_reaches_the_source_only_kind():
+    """the one-wave kernel (source-only launches) reads the same records: a reseeded plan's flow is the oracle's for the new seeds"""
+    specs, fs, dur, _ = configs.config_specs(3, 3)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = 2500
+    eng = vs.Engine(0)
+    try:
+        plan = eng.plan(lanes, ns)
+        out = eng.dev_alloc(3 * ns * 2)
+        s1 = np.array([11, 22, 33], dtype=np.uint64)
+        plan.reseed(s1)
+        plan.launch(vs.VS_KIND_SOURCE, out)
+        eng.synchronize()
+        got = eng.dev_download(out, (3, ns), np.int16)
+        eng.dev_free(out)
+        plan.close()
+        view = np.frombuffer(lanes, dtype=np.dtype(vs.Lane))
+        view["seed"] = s1
+        assert np.array_equal(got, po.source(lanes, ns))
+    finally:
+        eng.close()

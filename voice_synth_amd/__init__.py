@@ -419,6 +419,16 @@ class Plan:
         check(self._lib.vs_plan_roles(self._plan, C.byref(r), C.byref(l), C.byref(f)), "vs_plan_roles")
         return {"roles": r.value, "layout": "spread" if l.value else "role-major", "simd_fallback": bool(f.value)}
 
+    def reseed(self, seeds, out_seeds=None):
+        """vs_plan_reseed(): the same utterances with new draws -- seeds[i] (uint64) belongs to lane i of the plan's lane array"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n_lanes,)
+        if out_seeds is not None:
+            out_seeds = np.ascontiguousarray(out_seeds, dtype=np.uint64)
+            assert out_seeds.shape == (self.n_lanes,)
+        check(self._lib.vs_plan_reseed(self._plan, seeds.ctypes.data, out_seeds.ctypes.data if out_seeds is not None else None),
+              "vs_plan_reseed")
+
     def info(self):
         lds, wgs, slots = C.c_size_t(), C.c_size_t(), C.c_size_t()
         check(self._lib.vs_plan_info(self._plan, C.byref(lds), C.byref(wgs), C.byref(slots)), "vs_plan_info")

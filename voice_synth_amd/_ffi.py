@@ -191,6 +191,7 @@ SYMBOLS = {
     ),
     "vs_ctx_synchronize": (C.c_int, [_vp]),
     "vs_plan_status": (C.c_int, [_vp, _P(C.c_int)]),
+    "vs_plan_reseed": (C.c_int, [_vp, _vp, _vp]),
     "vs_plan_info": (C.c_int, [_vp, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t)]),
     "vs_synth": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp]),
     "vs_synth_rows": (C.c_int, [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, _vp]),

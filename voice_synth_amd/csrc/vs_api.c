@@ -729,6 +729,9 @@ void vs_plan_destroy(vs_plan *p)
     if (p->d_awide) (void)hipFree(p->d_awide);
   }
   if (p->d_sink) (void)hipFree(p->d_sink);
+  if (p->d_seeds) (void)hipFree(p->d_seeds);
+  if (p->h_seeds) (void)hipHostFree(p->h_seeds);
+  if (p->seeds_copied) (void)hipEventDestroy(p->seeds_copied);
   if (p->d_group_map) (void)hipFree(p->d_group_map);
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
@@ -750,6 +753,32 @@ int vs_plan_status(vs_plan *p, int *flags)
   }
   if (flags) *flags = word;
   return word ? VS_ERR_INTERNAL : VS_OK;
+}
+
+int vs_plan_reseed(vs_plan *p, const uint64_t *seeds, const uint64_t *out_seeds)
+{
+  if (!p || !seeds) return VS_ERR_ARG;
+  if (p->filter_only && !out_seeds) out_seeds = seeds;
+  if (!out_seeds) out_seeds = seeds;
+  vs_ctx *ctx = p->ctx;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n = p->n_lanes;
+  if (p->zc_host) return VS_ERR_INTERNAL; /* (the small calls' zero-copy plans live for one call inside vs_source / vs_filter) */
+  if (!p->d_seeds) {
+    VS_HIP(ctx, hipMalloc((void **)&p->d_seeds, 2 * n * sizeof(uint64_t)));
+    VS_HIP(ctx, hipHostMalloc((void **)&p->h_seeds, 2 * n * sizeof(uint64_t), hipHostMallocDefault));
+    VS_HIP(ctx, hipEventCreateWithFlags(&p->seeds_copied, hipEventDisableTiming));
+  } else {
+    VS_HIP(ctx, hipEventSynchronize(p->seeds_copied)); /* the previous reseed's upload has left the pinned buffer */
+  }
+  /* the caller's arrays are his again when this returns: they go through the plan's pinned buffer */
+  memcpy(p->h_seeds, seeds, n * sizeof(uint64_t));
+  memcpy(p->h_seeds + n, out_seeds, n * sizeof(uint64_t));
+  /* on the launch stream: behind the launches that still read the old seeds, in front of the next one */
+  VS_HIP(ctx, hipMemcpyAsync(p->d_seeds, p->h_seeds, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+  VS_HIP(ctx, hipEventRecord(p->seeds_copied, ctx->stream));
+  VS_HIP(ctx, vs_launch_reseed(p->d_lanes, p->d_seeds, p->d_seeds + n, (int)n, ctx->stream));
+  return VS_OK;
 }
 
 /* diagnostic builds (tools/diag_bench.py): device buffer of grid*8 uint64 cycle counters */

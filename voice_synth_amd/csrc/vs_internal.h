@@ -98,6 +98,9 @@ struct vs_plan {
   size_t flow_pitch;
   int owns_flow;     /* d_flow was allocated for this plan (else: the context pool's, shared by the pipeline's chunk plans) */
   vs_tuning tuning;  /* the context's tuning when the plan was made */
+  unsigned long long *d_seeds; /* vs_plan_reseed: [2][n_lanes] seeds / out_seeds on the device, allocated with the first reseed */
+  unsigned long long *h_seeds; /* ... and in pinned host memory: the caller's arrays are copied there, so they are his again at once */
+  hipEvent_t seeds_copied;     /* the upload out of h_seeds has run (a second reseed waits for it before it overwrites h_seeds) */
   void *zc_host;     /* zero-copy plans: lane records, cos rows, error word (and wide taps) in one pinned, device-mapped host block */
   int *zc_err;       /* ... the error word as the host sees it */
   double host_ms;    /* host time of vs_plan_create: expansion, sorting, tables */
@@ -119,6 +122,8 @@ extern "C" {
 #endif
 hipError_t vs_launch_selftest(unsigned long long *bad_dev, hipStream_t stream);
 hipError_t vs_launch_simd_probe(int waves, unsigned grid, size_t lds_bytes, unsigned *out_dev, hipStream_t stream);
+hipError_t vs_launch_reseed(VsDevLane *lanes, const unsigned long long *seeds, const unsigned long long *out_seeds,
+                            int n_lanes, hipStream_t stream);
 hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream);
 hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args, unsigned grid, hipStream_t stream);
 hipError_t vs_launch_kernel(int arith, int kind, bool log, bool wave_specialised, bool pre1, const VsKernelArgs *args,

@@ -1076,6 +1076,27 @@ __global__ void __launch_bounds__(1024) vs_simd_probe_kernel(unsigned *out)
   __syncthreads(); /* every wavefront of the workgroup is resident at the same time */
 }
 
+/* vs_plan_reseed: record i takes the seeds of the lane it was made from (VsDevLane.row) */
+__global__ void __launch_bounds__(256) vs_reseed_kernel(VsDevLane *lanes, const unsigned long long *seeds,
+                                                        const unsigned long long *out_seeds, int n_lanes)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)n_lanes) return;
+  VsDevLane *L = lanes + i;
+  const unsigned long long s = seeds[L->row], o = out_seeds[L->row];
+  L->key0 = (uint32_t)s;
+  L->key1 = (uint32_t)(s >> 32);
+  L->okey0 = (uint32_t)o;
+  L->okey1 = (uint32_t)(o >> 32);
+}
+
+extern "C" hipError_t vs_launch_reseed(VsDevLane *lanes, const unsigned long long *seeds, const unsigned long long *out_seeds,
+                                       int n_lanes, hipStream_t stream)
+{
+  hipLaunchKernelGGL(vs_reseed_kernel, dim3((unsigned)((n_lanes + 255) / 256)), dim3(256), 0, stream, lanes, seeds, out_seeds, n_lanes);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t vs_launch_simd_probe(int waves, unsigned grid, size_t lds_bytes, unsigned *out_dev, hipStream_t stream)
 {
   if (waves < 1 || waves > 16) return hipErrorInvalidValue;
