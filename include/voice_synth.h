@@ -191,7 +191,7 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
  * measurements (tools/) and tests.  Values are validated here, once, and copied into every plan
  * made afterwards; nothing else can change what a plan launches -- in particular no environment
  * variable does, unless VS_DEBUG_TUNING=1 asks vs_ctx_create() to read the experiment knobs
- * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_WS_ROLES, VS_GEN_LOW, VS_GEN_MIN, VS_WS_PRIO) through this
+ * (VS_KERNEL, VS_RING_SLOTS, VS_READY_MIN, VS_WS_PAIRS, VS_WS_ROLES, VS_GEN_LOW, VS_GEN_MIN, VS_WS_PRIO, VS_MIXED_RINGS) through this
  * same function.  NULL resets. */
 #define VS_KERNEL_AUTO 0
 #define VS_KERNEL_SINGLE 1 /* one wavefront per 64 utterances generates and filters */
