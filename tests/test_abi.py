@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_sizes_match_the_header():
     assert C.sizeof(_ffi.Lane) == 9 * 4 + 3 * 4 + 8 + 4 * 4 + 41 * 8 + 2 * 4 + 8   # 416 bytes
     assert C.sizeof(_ffi.CycleRec) == 16
-    assert C.sizeof(_ffi.DevLane) == 296
+    assert C.sizeof(_ffi.DevLane) == 128
     assert C.sizeof(_ffi.Tuning) == 44
 
 

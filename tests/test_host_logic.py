@@ -170,7 +170,7 @@ def test_expand_lane_matches_reference_expressions():
     assert d.tbound == 159 and d.dcs == 0 and d.flags == 7 | _ffi.VS_DF_FAST
     assert d.thr == 1                                       # ceil(0.25): x < 0.25  <=>  x < 1
     assert (d.key0, d.key1) == (7, 0)
-    assert list(d.a) == list(vs.vowel_coefficients("2")[1:])
+    assert d.tap_row == vs.load().vs_vowel_index(ord("2")) == 4   # a i u 1 2 ...: the plan's tap table row
     row = (C.c_double * d.T2)()
     vs.load().vs_cos_row(d.T2, row)
     assert list(row) == [math.cos(4.0 * math.atan(1.0) * k / d.T2) for k in range(d.T2)]
@@ -216,20 +216,35 @@ def test_cli_usage_text_equals_reference():
 
 
 def test_expand_lane_pads_a_low_order_set_with_zeros():
-    """an explicit set of fewer than 22 taps rides the order-22 kernels: taps behind its order are
-    zeros in the device record (acc - 0*y == acc)"""
+    """an explicit set of fewer than 22 taps rides the order-22 kernels: taps behind its order are zeros in its row of
+    the plan's tap table (acc - 0*y == acc); rows 0..9 of that table are the reference's ten tables (vw:450-544)"""
     from voice_synth_amd import configs
+    lib = vs.load()
     lanes, fs, dur = configs.wide_order_lanes([5, 22, 40])
-    d = _ffi.DevLane()
-    assert vs.load().vs_expand_lane(C.byref(lanes[0]), 0, C.byref(d)) == 0
-    assert [d.a[j] for j in range(5)] == [lanes[0].A[j + 1] for j in range(5)]
-    assert all(d.a[j] == 0.0 for j in range(5, 22))
-    assert vs.load().vs_expand_lane(C.byref(lanes[1]), 1, C.byref(d)) == 0
-    assert [d.a[j] for j in range(22)] == [lanes[1].A[j + 1] for j in range(22)]
+    recs = (_ffi.DevLane * 3)()
+    for i in range(3):
+        assert lib.vs_expand_lane(C.byref(lanes[i]), i, C.byref(recs[i])) == 0
+        assert recs[i].tap_row == -1 and recs[i].row == i
+    taps, rows = C.POINTER(C.c_double)(), C.c_size_t()
+    assert lib.vs_tap_table_build(lanes, recs, 3, 3, C.byref(taps), C.byref(rows)) == 0
+    assert rows.value == 13 and [recs[i].tap_row for i in range(3)] == [10, 11, 12]
+    row = lambda r: [taps[r * 22 + j] for j in range(22)]
+    assert row(10)[:5] == [lanes[0].A[j + 1] for j in range(5)] and all(x == 0.0 for x in row(10)[5:])
+    assert row(11) == [lanes[1].A[j + 1] for j in range(22)]
     # a wide set expands too (its first 22 taps; the plan carries all 40 separately)
-    assert vs.load().vs_expand_lane(C.byref(lanes[2]), 2, C.byref(d)) == 0
+    assert row(12) == [lanes[2].A[j + 1] for j in range(22)]
+    A = (C.c_double * 41)()
+    for t in range(10):
+        v = lib.vs_vowel_by_index(t)
+        assert lib.vs_vowel_index(v) == t and lib.vs_vowel_coefficients(v, A) == 0
+        assert row(t) == [A[j + 1] for j in range(22)]
+    assert lib.vs_vowel_index(ord("A")) == -1 and lib.vs_vowel_by_index(10) == 0
+    C.CDLL(None).free(taps)
+    d = _ffi.DevLane()
     lanes[2].order = 41
-    assert vs.load().vs_expand_lane(C.byref(lanes[2]), 2, C.byref(d)) == _ffi.VS_ERR_RANGE
+    assert lib.vs_expand_lane(C.byref(lanes[2]), 2, C.byref(d)) == _ffi.VS_ERR_RANGE
+    lane, _ = vs.lane_from_cli(["-r", "16000", "-d", "1"], ["-v", "a"], 0)
+    assert lib.vs_expand_lane(C.byref(lane), 0, C.byref(d)) == 0 and d.tap_row == 0
 
 
 def test_integration_md_snippets_compile(tmp_path):

@@ -93,7 +93,6 @@ class DevLane(C.Structure):
     """struct VsDevLane of csrc/vs_device.h (host expansion of a lane; CPU-side tests only)."""
 
     _fields_ = [
-        ("a", C.c_double * 22),
         ("gain", C.c_double),
         ("pre", C.c_double),
         ("jitter", C.c_float),
@@ -122,6 +121,8 @@ class DevLane(C.Structure):
         ("okey1", C.c_uint32),
         ("thr", C.c_int32),
         ("ready_min", C.c_int32),
+        ("tap_row", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -231,6 +232,9 @@ INTERNAL_SYMBOLS = {
     "vs_expand_lane": (C.c_int, [_P(Lane), C.c_int32, _P(DevLane)]),
     "vs_cos_row": (None, [C.c_int, _P(C.c_double)]),
     "vs_ring_slots_for": (C.c_int, [C.c_int, _P(C.c_int)]),
+    "vs_tap_table_build": (C.c_int, [_P(Lane), _P(DevLane), C.c_size_t, C.c_size_t, _P(_P(C.c_double)), _P(C.c_size_t)]),
+    "vs_vowel_index": (C.c_int, [C.c_int]),
+    "vs_vowel_by_index": (C.c_int, [C.c_int]),
 }
 
 _lib = None

@@ -383,6 +383,27 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       dl[l].tab_off = row_of_T2[T2];
     }
   }
+  /* the tap table rides behind the cos rows (one allocation, one copy): a spare entry, then rows 0..9 the ten tables,
+   * then the lanes' own sets; records with a set of their own learn their row here */
+  size_t taps_off = 0;
+  {
+    double *taps = NULL;
+    size_t tap_rows = 0;
+    rc = vs_tap_table_build(lanes, dl, n_lanes, st.n_custom, &taps, &tap_rows);
+    if (rc != VS_OK) goto done;
+    taps_off = costab_len + 1;
+    double *grown = (double *)realloc(costab, (taps_off + tap_rows * VS_ORDER) * sizeof(double));
+    if (!grown) {
+      free(taps);
+      rc = VS_ERR_NOMEM;
+      goto done;
+    }
+    costab = grown;
+    costab[costab_len] = 0.0;
+    memcpy(costab + taps_off, taps, tap_rows * VS_ORDER * sizeof(double));
+    costab_len = taps_off + tap_rows * VS_ORDER; /* what goes up; the cos rows end at taps_off - 1 */
+    free(taps);
+  }
   const bool pre1 = st.pre1 != 0;
   const bool wide = st.wide != 0;
   if (!any_onoise) min_lframe = 0;
@@ -645,12 +666,14 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       p->d_costab = (double *)(db + zc_off_cos);
       p->d_err = (int *)(db + zc_off_err);
       if (wide) p->d_awide = (double *)(db + zc_off_wide);
+      p->d_taps = p->d_costab + taps_off;
     }
   } else {
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab_len + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
     if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
+    if (e == hipSuccess) p->d_taps = p->d_costab + taps_off;
   }
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
   if (e == hipSuccess && gmap) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
@@ -849,6 +872,7 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   memset(&a, 0, sizeof(a));
   a.lanes = p->d_lanes;
   a.costab = p->d_costab;
+  a.taps = p->d_taps;
   a.in = in_dev;
   a.out = out_dev;
   a.log = (kind == VS_KIND_FILTER) ? NULL : (void *)log_dev;

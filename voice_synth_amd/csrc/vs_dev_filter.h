@@ -8,12 +8,14 @@
 
 /* the lane's 22 taps as vs_superstep wants them: A[1..22] for VS_ARITH_EXACT, -A[1..22] for VS_ARITH_FMA */
 template <int ARITH>
-__device__ __forceinline__ void vs_load_taps(const VsDevLane *__restrict__ L, double (&a)[VS_ORDER + 1])
+__device__ __forceinline__ void vs_load_taps(const double *__restrict__ taps, const VsDevLane *__restrict__ L,
+                                             double (&a)[VS_ORDER + 1])
 {
+  const double *__restrict__ row = taps + (size_t)L->tap_row * VS_ORDER; /* the lane's row of the plan's tap table */
   a[0] = 1.0;
 #pragma unroll
   for (int j = 1; j <= VS_ORDER; ++j) {
-    a[j] = (ARITH == VS_ARITH_FMA) ? -L->a[j - 1] : L->a[j - 1];
+    a[j] = (ARITH == VS_ARITH_FMA) ? -row[j - 1] : row[j - 1];
     /* the sign goes INTO the register: left to itself the compiler keeps +A and folds the negation back into every
      * multiply-add as a source modifier -- free, but only the 8-byte encoding has modifiers */
     if (ARITH == VS_ARITH_FMA) asm volatile("" : "+v"(a[j]));

@@ -33,11 +33,14 @@
 
 #define VS_TRASH_ROWS 8 /* ring rows [C, C+8): where lanes that must not emit send their 8-sample trips */
 
-/* One utterance as the kernel reads it (296 bytes, 8-byte aligned).  Everything that is a
+/* One utterance as the kernel reads it (128 bytes, 8-byte aligned).  Everything that is a
  * pure function of the lane's parameters is evaluated on the host, in C, with the reference's
- * operand types (vs_expand_lane() in vs_api.c). */
+ * operand types (vs_expand_lane() in vs_planhost.c).  The 22 taps of its filter are NOT in the record: they are a row of
+ * the plan's tap table (VsKernelArgs.taps) -- rows 0..9 the reference's ten tables in the order of vs_vowel_by_index(),
+ * one more row per utterance that brings a coefficient set of its own -- so that 65536 utterances on five tables move
+ * 8 MB of records through the host and over PCIe instead of 19. */
+#define VS_TAP_TABLE_ROWS 10
 typedef struct VsDevLane {
-  double a[22];       /* A[1..22]                                      vowel_new.c:279-281 */
   double gain;        /* (double)gain                                  vowel_new.c:268 */
   double pre;         /* (double)pre_emphasis                          vowel_new.c:284 */
   float jitter, shimmer, K, Kvar, DC, noise;
@@ -57,6 +60,8 @@ typedef struct VsDevLane {
   uint32_t okey0, okey1; /* Philox key of the vowel stage's draw stream */
   int32_t thr;        /* ceil(par.DC) as an integer: for an integer x, (float)x < par.DC  <=>  x < thr   (fg:320, 329) */
   int32_t ready_min;  /* super-step threshold of this lane's 64-utterance group (the same in all its lanes): ready lanes * 64 >= live lanes * ready_min */
+  int32_t tap_row;    /* row of A[1..22] in the plan's tap table (vowel_new.c:279-281); from vs_expand_lane: 0..9 = a table, -1 = a set of the lane's own (the plan gives it a row) */
+  int32_t reserved;
 } VsDevLane;
 
 /* Wave-specialised launches whose groups differ in period (an F0 sweep): one record per (workgroup, slot) -- which
@@ -100,6 +105,7 @@ typedef struct VsKernelArgs {
   int16_t *sink;       /* one row of n_samples + 32 samples nobody reads: where the lanes beyond n_lanes of the last group store (wave-specialised kernels) */
   const double *awide; /* wide plans (a coefficient set of 23..40 taps): A[1..40] per lane record, zeros behind its order */
   int ws_layout;       /* wave-specialised kernels, how a workgroup's wavefronts map to roles: VS_WS_LAYOUT_* */
+  const double *taps;  /* the plan's tap table: [rows][22], A[1..22] of row VsDevLane.tap_row */
   const VsGroupSlot *group_map; /* mixed rings: [workgroups][ws_pairs]; NULL: group = workgroup * ws_pairs + slot, uniform rings */
 } VsKernelArgs;
 

@@ -98,6 +98,15 @@ int vs_vowel_coefficients(int vowel, double *A)
   return VS_ERR_RANGE;
 }
 
+/* the ten tables by number, 0..9 in the order of the table ids (a i u 1..7): the rows of a plan's tap table */
+int vs_vowel_index(int vowel)
+{
+  for (int t = 0; t < VS_TAB_NTABLES; t++)
+    if (vs_tab_ids[t] == (char)vowel) return t;
+  return -1;
+}
+int vs_vowel_by_index(int index) { return (index >= 0 && index < VS_TAB_NTABLES) ? (int)vs_tab_ids[index] : 0; }
+
 const char *vs_vowel_name(int vowel)
 {
   for (int t = 0; t < VS_TAB_NTABLES; t++)

@@ -70,6 +70,7 @@ struct vs_plan {
   size_t n_lanes, n_samples;
   VsDevLane *d_lanes;
   double *d_costab;
+  double *d_taps;    /* the tap table: [rows][22] (rows 0..9 the ten tables, then the lanes' own sets) */
   int ring_slots;
   int ready_min;
   int ltab_entries;

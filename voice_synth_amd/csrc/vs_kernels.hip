@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
   /* filter constants and state in registers */
   double a[VS_ORDER + 1];
   double y[VS_SS];
-  vs_load_taps<ARITH>(L, a);
+  vs_load_taps<ARITH>(args.taps, L, a);
 #pragma unroll
   for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
   const double gain = L->gain;
@@ -498,7 +498,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
   else if (args.ws_filter_prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (args.ws_filter_prio == 1) __builtin_amdgcn_s_setprio(1);
   double a[VS_ORDER + 1];
-  vs_load_taps<ARITH>(L, a);
+  vs_load_taps<ARITH>(args.taps, L, a);
   const double gain = L->gain;
   const double pre = L->pre;
   int16_t *orow = args.out + g.row * args.out_pitch;

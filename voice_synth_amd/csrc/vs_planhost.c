@@ -44,10 +44,11 @@ int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 {
   int rc = vs_lane_validate(lane);
   if (rc != VS_OK) return rc;
-  double A[VS_MAX_NCOEF];
-  if ((rc = vs_lane_taps(lane, A)) != VS_OK) return rc;
   memset(d, 0, sizeof(*d));
-  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j]; /* a wide set's first 22 taps: unused, the plan is wide */
+  /* the taps are a row of the plan's table: one of the ten tables, or (-1) a row the plan makes for this lane's own
+   * set (vs_tap_table_build; vs_lane_validate has been through the set) */
+  d->tap_row = (lane->vowel == VS_VOWEL_CUSTOM) ? -1 : vs_vowel_index(lane->vowel);
+  if (lane->vowel != VS_VOWEL_CUSTOM && d->tap_row < 0) return VS_ERR_RANGE; /* cannot happen behind vs_lane_validate */
   d->gain = (double)lane->gain;
   d->pre = (double)lane->pre_emphasis;
   d->jitter = lane->jitter;
@@ -163,7 +164,6 @@ int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
 {
   if (!(lane->pre_emphasis >= 0.0 && lane->pre_emphasis <= 1.0)) return VS_ERR_RANGE; /* vw:127 */
   if (!(lane->gain >= 1)) return VS_ERR_RANGE;                                        /* vw:132 */
-  double A[VS_MAX_NCOEF];
   if (lane->vowel == VS_VOWEL_CUSTOM) {
     int order = 0;
     const int rc = vs_lane_order(lane, &order);
@@ -171,14 +171,12 @@ int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
     for (int j = 0; j <= order; j++)
       if (!isfinite(lane->A[j])) return VS_ERR_RANGE;
     if (lane->A[0] != 1.0) return VS_ERR_RANGE;
-  }
-  {
-    const int rc = vs_lane_taps(lane, A);
-    if (rc != VS_OK) return (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') ? VS_ERR_UNSUPPORTED : VS_ERR_RANGE;
+  } else if (vs_vowel_index(lane->vowel) < 0) {
+    return (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') ? VS_ERR_UNSUPPORTED : VS_ERR_RANGE;
   }
   if (lane->fs <= 0) return VS_ERR_RANGE;
   memset(d, 0, sizeof(*d));
-  for (int j = 1; j <= VS_ORDER; j++) d->a[j - 1] = A[j];
+  d->tap_row = (lane->vowel == VS_VOWEL_CUSTOM) ? -1 : vs_vowel_index(lane->vowel);
   d->gain = (double)lane->gain;
   d->pre = (double)lane->pre_emphasis;
   d->row = row;
@@ -222,6 +220,7 @@ static void stats_lane(VsBatchStats *st, const vs_lane *lane, const VsDevLane *d
   if (d->out_snr > 0) st->any_onoise = 1;
   if (d->pre != 1.0) st->pre1 = 0;
   if (vs_lane_is_wide(lane)) st->wide = 1;
+  if (d->tap_row < 0) st->n_custom++;
   if (d->flags & VS_DF_NOISE) st->n_noisy++;
 }
 static void stats_merge(VsBatchStats *a, const VsBatchStats *b)
@@ -233,6 +232,43 @@ static void stats_merge(VsBatchStats *a, const VsBatchStats *b)
   a->pre1 &= b->pre1;
   a->wide |= b->wide;
   a->n_noisy += b->n_noisy;
+  a->n_custom += b->n_custom;
+}
+
+int vs_tap_table_build(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, size_t n_custom, double **taps_out, size_t *rows_out)
+{
+  if (!lanes || !dl || !taps_out || !rows_out) return VS_ERR_ARG;
+  const size_t rows = VS_TAP_TABLE_ROWS + n_custom;
+  double *taps = (double *)malloc(rows * VS_ORDER * sizeof(double));
+  if (!taps) return VS_ERR_NOMEM;
+  double A[VS_MAX_NCOEF];
+  for (int t = 0; t < VS_TAP_TABLE_ROWS; t++) {
+    if (vs_vowel_coefficients(vs_vowel_by_index(t), A) != VS_OK) {
+      free(taps);
+      return VS_ERR_INTERNAL;
+    }
+    for (int j = 1; j <= VS_ORDER; j++) taps[(size_t)t * VS_ORDER + (size_t)(j - 1)] = A[j];
+  }
+  size_t next = VS_TAP_TABLE_ROWS;
+  for (size_t i = 0; i < n_lanes && n_custom; i++) {
+    if (dl[i].tap_row >= 0) continue;
+    if (next >= rows) { /* more sets than the count said: cannot happen */
+      free(taps);
+      return VS_ERR_INTERNAL;
+    }
+    const int rc = vs_lane_taps(&lanes[(size_t)dl[i].row], A); /* zeros behind the set's order: acc - 0*y == acc */
+    if (rc != VS_OK) {
+      free(taps);
+      return rc;
+    }
+    /* (a wide set's first 22 taps: unused, the wide kernel reads all 40 from the plan's other table) */
+    for (int j = 1; j <= VS_ORDER; j++) taps[next * VS_ORDER + (size_t)(j - 1)] = A[j];
+    dl[i].tap_row = (int32_t)next;
+    next++;
+  }
+  *taps_out = taps;
+  *rows_out = rows;
+  return VS_OK;
 }
 
 static void *expand_range(void *arg)

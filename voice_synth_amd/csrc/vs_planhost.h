@@ -16,6 +16,13 @@ extern "C" {
 #endif
 /* A[0..40] of the lane's filter: the table or the explicit set, zeros behind its order */
 int vs_lane_taps(const vs_lane *lane, double *A);
+/* the ten tables by number (csrc/vs_host.c): 0..9, -1 / 0 for anything else */
+int vs_vowel_index(int vowel);
+int vs_vowel_by_index(int index);
+/* The plan's tap table: rows 0..9 the ten tables, then one row per record whose tap_row is -1 (a coefficient set of the
+ * lane's own, taken from lanes[record.row]; the record learns its row).  *taps is malloc'ed ([*rows][22] doubles, A[1..22]),
+ * the caller frees it. */
+int vs_tap_table_build(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, size_t n_custom, double **taps, size_t *rows);
 bool vs_lane_is_wide(const vs_lane *lane);
 /* one lane -> the record the kernels read (validated); the filter-only form fills what vowel reads */
 int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
@@ -30,6 +37,7 @@ typedef struct VsBatchStats {
   int pre1;         /* every lane has pre_emphasis == 1.0 */
   int wide;         /* some lane carries a coefficient set of 23..40 taps */
   size_t n_noisy;   /* lanes with glottal noise (VS_DF_NOISE) */
+  size_t n_custom;  /* lanes that bring a coefficient set of their own (tap_row -1) */
 } VsBatchStats;
 /* all lanes, cut over up to 16 host threads for batches >= 8192; the failure of the lowest lane wins; stats may be NULL */
 int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only);
