@@ -181,6 +181,35 @@ int main(void)
     for (int i = 0; i < 40; i++) CHECK(out[i].row == i && out[i].key0 == (uint32_t)(100 + i));
   }
 
+  /* ONE workspace over batches of growing and shrinking size (what a context does: chunks of 16384 lanes, then a
+   * whole batch): every answer equals the one-shot function's, whichever buffers the workspace already holds */
+  {
+    VsPlanWs *ws = vs_planws_create();
+    CHECK(ws != NULL);
+    const size_t sizes[] = {300, 9000, 64, 20000, 8192, 1, 20000};
+    VsDevLane *want = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+    CHECK(want != NULL);
+    for (size_t k = 0; k < sizeof(sizes) / sizeof(sizes[0]); k++) {
+      const size_t m = sizes[k];
+      VsDevLane *got = NULL;
+      VsBatchStats sa, sb;
+      int ra = -1, rb = -1;
+      CHECK(vs_expand_all_ordered_ws(ws, lanes, m, 0, &got, &ra, &sa) == VS_OK && got != NULL);
+      CHECK(vs_expand_all_ordered(lanes, want, m, &rb, &sb) == VS_OK);
+      CHECK(ra == rb && memcmp(&sa, &sb, sizeof(sa)) == 0);
+      if (got) CHECK(memcmp(got, want, m * sizeof(VsDevLane)) == 0);
+      CHECK(vs_expand_all_ordered_ws(ws, lanes, m, 1, &got, &ra, NULL) == VS_OK && ra == 0); /* filter-only: input order */
+      CHECK(vs_expand_all(lanes, want, m, 1) == VS_OK);
+      if (got) CHECK(memcmp(got, want, m * sizeof(VsDevLane)) == 0);
+    }
+    VsDevLane *got = NULL;
+    CHECK(vs_expand_all_ordered_ws(ws, lanes, 0, 0, &got, NULL, NULL) == VS_ERR_ARG);
+    CHECK(vs_expand_all_ordered_ws(NULL, lanes, 5, 0, &got, NULL, NULL) == VS_ERR_ARG);
+    free(want);
+    vs_planws_destroy(ws);
+    vs_planws_destroy(NULL);
+  }
+
   /* two bad lanes met by different threads: the lowest one's error is the answer */
   lanes[17000].F0 = 10.0f;                   /* below 50: VS_ERR_RANGE */
   lanes[3000].cq = 0.0f;                     /* no pulse: VS_ERR_UNSUPPORTED */

@@ -142,7 +142,7 @@ void vs_ctx_destroy(vs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamDestroy(ctx->own_upload);
   }
-  free(ctx->plan_scratch);
+  vs_planws_destroy(ctx->planws);
   free(ctx);
 }
 
@@ -321,32 +321,27 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   }
   const vs_tuning *tune = &ctx->tuning;
   int rc = VS_OK;
-  /* the records are made in host memory the context keeps between plans (grown on demand, released by
-   * vs_ctx_destroy: a fresh 19 MB block per plan is thousands of page faults); everything else of this call is
-   * released at `done` */
-  if (ctx->plan_scratch_bytes < n_lanes * sizeof(VsDevLane)) {
-    free(ctx->plan_scratch);
-    ctx->plan_scratch_bytes = 0;
-    ctx->plan_scratch = malloc(n_lanes * sizeof(VsDevLane));
-    if (ctx->plan_scratch) ctx->plan_scratch_bytes = n_lanes * sizeof(VsDevLane);
-  }
-  VsDevLane *dl = (VsDevLane *)ctx->plan_scratch;
+  /* the records are made in the context's plan workspace (csrc/vs_planhost.c: worker threads that sleep between plans,
+   * record buffers that are kept -- a fresh 8 MB block per plan is two thousand page faults); everything else of this
+   * call is released at `done` */
+  if (!ctx->planws) ctx->planws = vs_planws_create();
+  if (!ctx->planws) return VS_ERR_NOMEM;
+  VsDevLane *dl = NULL;
   double *costab = NULL;   /* the cos rows, one per distinct T2 */
   size_t costab_len = 0, costab_cap = 0;
   int *row_of_T2 = NULL;   /* first entry of the row of T2 in costab, -1: not built yet */
   double *awide = NULL;    /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
   VsGroupSlot *gmap = NULL; /* mixed rings: which group, which ring depth, which LDS region per (workgroup, slot) */
   vs_plan *p = NULL;
-  if (!dl) return VS_ERR_NOMEM;
   const double t_host0 = vs_now_ms();
   /* Wavefronts are formed from lanes with similar periods: a generator round costs as much as its longest lane and
    * the cos rows of a wavefront are staged once per distinct T2, so a batch with an F0 sweep (BASELINE config 5) is
-   * put in the order of (P, T2, options) before it is cut into groups of 64 -- the records are written straight into
-   * that order (vs_expand_all_ordered).  Placement is internal: each lane still writes its own output row
-   * (VsDevLane.row), and a lane's result does not depend on its neighbours.  Stable, so homogeneous batches keep
-   * their order. */
-  VsBatchStats st; /* gathered by the threads that make the records: no walk over 19 MB of them per question */
-  rc = filter_only ? vs_expand_all_stats(lanes, dl, n_lanes, 1, &st) : vs_expand_all_ordered(lanes, dl, n_lanes, NULL, &st);
+   * put in the order of (P, T2, options) before it is cut into groups of 64 (vs_expand_all_ordered_ws: one parallel
+   * pass makes the records, a batch whose keys differ is then sorted and gathered).  Placement is internal: each lane
+   * still writes its own output row (VsDevLane.row), and a lane's result does not depend on its neighbours.  Stable, so
+   * homogeneous batches keep their order. */
+  VsBatchStats st; /* gathered by the threads that make the records: no walk over all of them per question */
+  rc = vs_expand_all_ordered_ws(ctx->planws, lanes, n_lanes, filter_only, &dl, NULL, &st);
   if (rc != VS_OK) goto done;
 
   /* every lane of a launch with output noise accumulates its frame powers, so the rows of the power table must hold

@@ -135,8 +135,7 @@ int vs_lane_validate(const vs_lane *lane)
   if (!(lane->pre_emphasis >= 0.0 && lane->pre_emphasis <= 1.0)) return VS_ERR_RANGE; /* vw:127 */
   if (!(lane->gain >= 1)) return VS_ERR_RANGE;                                        /* vw:132 */
   if (lane->vowel != VS_VOWEL_CUSTOM) {
-    double A[VS_NCOEF];
-    if (vs_vowel_coefficients(lane->vowel, A) != VS_OK) {
+    if (vs_vowel_index(lane->vowel) < 0) { /* not one of the ten tables */
       /* upper-case A/I/U pass the reference's check but load no coefficients */
       if (lane->vowel == 'A' || lane->vowel == 'I' || lane->vowel == 'U') return VS_ERR_UNSUPPORTED;
       return VS_ERR_RANGE;

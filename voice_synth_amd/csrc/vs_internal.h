@@ -53,8 +53,7 @@ struct vs_ctx {
   int cu_count;
   vs_tuning tuning; /* all zero = the library's own choices */
   VsPool pool;
-  void *plan_scratch;     /* host memory of vs_plan_create between calls: the lane records on their way to the device */
-  size_t plan_scratch_bytes; /* (a fresh 19 MB malloc per plan is 4750 page faults; a context is used by one thread at a time) */
+  struct VsPlanWs *planws; /* plan creation's worker threads and host buffers between calls (csrc/vs_planhost.c; a context is used by one thread at a time) */
   int copy_warm;          /* the runtime's copy path has been set up (vs_copy_path_warm) */
   double copy_warm_ms;    /* ... and what that cost */
   /* where the hardware deals the wavefronts of a workgroup (vs_ctx_simd_dealing): asked once, the first time a

@@ -204,6 +204,8 @@ typedef struct ExpandJob {
   int rc;          /* the failure of the LOWEST lane met in [lo, hi) */
   size_t bad;      /* ... and that lane */
   VsBatchStats st; /* of the records this job made */
+  uint64_t *key;   /* NULL, or where the order key of record i goes */
+  uint64_t key_or, key_and; /* over the keys this job wrote */
 } ExpandJob;
 
 static void stats_init(VsBatchStats *st)
@@ -271,11 +273,191 @@ int vs_tap_table_build(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, size
   return VS_OK;
 }
 
-static void *expand_range(void *arg)
+/* ------------------------------------------------------------------------------------------
+ * The plan workspace: worker threads that live as long as the context, and the host buffers a plan is made in
+ * ---------------------------------------------------------------------------------------- */
+/* Sixteen threads started and joined per plan cost more than the records they make (0.38 ms of 0.6, 16-core quota
+ * of an EPYC 9575F: tools/planhost_time.c), and a plan makes two parallel passes.  The team's threads sleep on a
+ * condition variable between passes; a pass is an array of jobs that the threads -- the caller among them -- take one
+ * by one. */
+typedef void (*vs_team_fn)(void *job);
+typedef struct VsTeam {
+  int n_workers; /* threads besides the caller */
+  pthread_t th[VS_EXPAND_THREADS - 1];
+  pthread_mutex_t mu;
+  pthread_cond_t go, done;
+  unsigned gen; /* passes started so far */
+  int pending;  /* workers that have not finished the current pass */
+  int stop;
+  vs_team_fn fn;
+  char *jobs;
+  size_t job_size;
+  int n_jobs, next; /* next: first job nobody has taken (under mu) */
+} VsTeam;
+
+static void team_take_jobs(VsTeam *t)
+{
+  for (;;) {
+    pthread_mutex_lock(&t->mu);
+    const int i = (t->next < t->n_jobs) ? t->next++ : -1;
+    pthread_mutex_unlock(&t->mu);
+    if (i < 0) return;
+    t->fn(t->jobs + (size_t)i * t->job_size);
+  }
+}
+static void *team_worker(void *arg)
+{
+  VsTeam *t = (VsTeam *)arg;
+  unsigned seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&t->mu);
+    while (t->gen == seen && !t->stop) pthread_cond_wait(&t->go, &t->mu);
+    if (t->stop) {
+      pthread_mutex_unlock(&t->mu);
+      return NULL;
+    }
+    seen = t->gen;
+    pthread_mutex_unlock(&t->mu);
+    team_take_jobs(t);
+    pthread_mutex_lock(&t->mu);
+    if (--t->pending == 0) pthread_cond_signal(&t->done);
+    pthread_mutex_unlock(&t->mu);
+  }
+}
+static VsTeam *team_create(void)
+{
+  long nt = sysconf(_SC_NPROCESSORS_ONLN);
+  if (nt > VS_EXPAND_THREADS) nt = VS_EXPAND_THREADS;
+  if (nt < 1) nt = 1;
+  VsTeam *t = (VsTeam *)calloc(1, sizeof(VsTeam));
+  if (!t) return NULL;
+  pthread_mutex_init(&t->mu, NULL);
+  pthread_cond_init(&t->go, NULL);
+  pthread_cond_init(&t->done, NULL);
+  for (long k = 0; k + 1 < nt; k++) { /* a thread that cannot be started is simply not there */
+    if (pthread_create(&t->th[t->n_workers], NULL, team_worker, t) != 0) break;
+    t->n_workers++;
+  }
+  return t;
+}
+static void team_destroy(VsTeam *t)
+{
+  if (!t) return;
+  pthread_mutex_lock(&t->mu);
+  t->stop = 1;
+  pthread_cond_broadcast(&t->go);
+  pthread_mutex_unlock(&t->mu);
+  for (int k = 0; k < t->n_workers; k++) pthread_join(t->th[k], NULL);
+  pthread_cond_destroy(&t->go);
+  pthread_cond_destroy(&t->done);
+  pthread_mutex_destroy(&t->mu);
+  free(t);
+}
+/* one pass: fn over jobs[0 .. n_jobs); returns when all of them are done.  No team (NULL), or a team without
+ * workers: the caller does them all. */
+static void team_run(VsTeam *t, vs_team_fn fn, void *jobs, size_t job_size, int n_jobs)
+{
+  if (!t || t->n_workers == 0 || n_jobs < 2) {
+    for (int i = 0; i < n_jobs; i++) fn((char *)jobs + (size_t)i * job_size);
+    return;
+  }
+  pthread_mutex_lock(&t->mu);
+  t->fn = fn;
+  t->jobs = (char *)jobs;
+  t->job_size = job_size;
+  t->n_jobs = n_jobs;
+  t->next = 0;
+  t->pending = t->n_workers;
+  t->gen++;
+  pthread_cond_broadcast(&t->go);
+  pthread_mutex_unlock(&t->mu);
+  team_take_jobs(t);
+  pthread_mutex_lock(&t->mu);
+  while (t->pending > 0) pthread_cond_wait(&t->done, &t->mu);
+  pthread_mutex_unlock(&t->mu);
+}
+
+struct VsPlanWs {
+  VsTeam *team;      /* made with the first batch of VS_TEAM_MIN_LANES lanes or more */
+  VsDevLane *rec[2]; /* the records in input order / in kernel order */
+  size_t rec_lanes;  /* lanes either holds */
+  uint64_t *key;     /* the order key of every lane */
+  uint32_t *idx[2];  /* radix sort of the lane indices */
+  size_t key_lanes, idx_lanes;
+  size_t *count;     /* 65537 digit counters */
+};
+#define VS_TEAM_MIN_LANES 8192
+#define VS_JOB_LANES 2048 /* lanes per job: 32 jobs for 65536 lanes -- a thread that comes late takes fewer of them */
+#define VS_MAX_JOBS 64
+
+VsPlanWs *vs_planws_create(void) { return (VsPlanWs *)calloc(1, sizeof(VsPlanWs)); }
+void vs_planws_destroy(VsPlanWs *ws)
+{
+  if (!ws) return;
+  team_destroy(ws->team);
+  free(ws->rec[0]);
+  free(ws->rec[1]);
+  free(ws->key);
+  free(ws->idx[0]);
+  free(ws->idx[1]);
+  free(ws->count);
+  free(ws);
+}
+/* the buffers for n lanes (grown, never shrunk: a fresh 8 MB block per plan is two thousand page faults) */
+static int ws_reserve(VsPlanWs *ws, size_t n, int need_order)
+{
+  if (ws->rec_lanes < n) {
+    for (int b = 0; b < 2; b++) {
+      free(ws->rec[b]);
+      ws->rec[b] = NULL;
+    }
+    ws->rec_lanes = 0;
+    ws->rec[0] = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+    if (!ws->rec[0]) return VS_ERR_NOMEM;
+    ws->rec_lanes = n;
+  }
+  if (need_order) {
+    if (!ws->rec[1]) {
+      ws->rec[1] = (VsDevLane *)malloc(ws->rec_lanes * sizeof(VsDevLane));
+      if (!ws->rec[1]) return VS_ERR_NOMEM;
+    }
+    if (ws->idx_lanes < n) {
+      free(ws->idx[0]);
+      free(ws->idx[1]);
+      ws->idx_lanes = 0;
+      ws->idx[0] = (uint32_t *)malloc(n * sizeof(uint32_t));
+      ws->idx[1] = (uint32_t *)malloc(n * sizeof(uint32_t));
+      if (!ws->idx[0] || !ws->idx[1]) return VS_ERR_NOMEM;
+      ws->idx_lanes = n;
+    }
+    if (!ws->count) ws->count = (size_t *)malloc(65537 * sizeof(size_t));
+    if (!ws->count) return VS_ERR_NOMEM;
+  }
+  if (ws->key_lanes < n) {
+    free(ws->key);
+    ws->key_lanes = 0;
+    ws->key = (uint64_t *)malloc(n * sizeof(uint64_t));
+    if (!ws->key) return VS_ERR_NOMEM;
+    ws->key_lanes = n;
+  }
+  return VS_OK;
+}
+
+/* the kernels' order key of a source record: (P, T2, jitter / shimmer / noise on) -- lane_order_key() below says the
+ * same of the lane it was made from */
+static uint64_t record_order_key(const VsDevLane *d)
+{
+  return ((uint64_t)(uint32_t)d->P << 36) | ((uint64_t)(uint32_t)d->T2 << 8) |
+         (uint64_t)(d->flags & (VS_DF_JITTER | VS_DF_SHIMMER | VS_DF_NOISE));
+}
+
+static void expand_range(void *arg)
 {
   ExpandJob *j = (ExpandJob *)arg;
   j->rc = VS_OK;
   j->bad = (size_t)-1;
+  j->key_or = 0;
+  j->key_and = ~(uint64_t)0;
   stats_init(&j->st);
   for (size_t i = j->lo; i < j->hi; i++) {
     const size_t l = j->order ? (size_t)j->order[i] : i;
@@ -290,75 +472,180 @@ static void *expand_range(void *arg)
       continue;
     }
     stats_lane(&j->st, &j->lanes[l], &j->dl[i]);
+    if (j->key) {
+      const uint64_t k = record_order_key(&j->dl[i]);
+      j->key[i] = k;
+      j->key_or |= k;
+      j->key_and &= k;
+    }
   }
-  return NULL;
 }
 
-static int expand_with_order(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, const uint32_t *order,
-                             VsBatchStats *stats)
+/* records [lo, hi) of the kernel order: out[i] = in[order[i]] */
+typedef struct GatherJob {
+  const VsDevLane *in;
+  VsDevLane *out;
+  const uint32_t *order;
+  size_t lo, hi;
+} GatherJob;
+static void gather_range(void *arg)
 {
-  long nt = 1;
-  if (n_lanes >= 8192) {
-    nt = sysconf(_SC_NPROCESSORS_ONLN);
-    if (nt > VS_EXPAND_THREADS) nt = VS_EXPAND_THREADS;
-    if (nt < 1) nt = 1;
-  }
-  ExpandJob jobs[VS_EXPAND_THREADS];
-  pthread_t th[VS_EXPAND_THREADS];
-  const size_t per = (n_lanes + (size_t)nt - 1) / (size_t)nt;
-  int started = 0, n_jobs = 0;
-  for (long t = 0; t < nt; t++) {
+  GatherJob *j = (GatherJob *)arg;
+  for (size_t i = j->lo; i < j->hi; i++) j->out[i] = j->in[j->order[i]];
+}
+
+static int jobs_for(size_t n_lanes, int parallel)
+{
+  if (!parallel) return 1;
+  size_t n = (n_lanes + VS_JOB_LANES - 1) / VS_JOB_LANES;
+  if (n > VS_MAX_JOBS) n = VS_MAX_JOBS;
+  return n ? (int)n : 1;
+}
+
+/* one parallel pass of expand_range over all lanes; key: NULL or where every record's order key goes */
+static int expand_pass(VsTeam *team, const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only,
+                       const uint32_t *order, uint64_t *key, uint64_t *varying, VsBatchStats *stats)
+{
+  ExpandJob jobs[VS_MAX_JOBS];
+  const int n_jobs = jobs_for(n_lanes, team != NULL);
+  const size_t per = (n_lanes + (size_t)n_jobs - 1) / (size_t)n_jobs;
+  int made = 0;
+  for (int t = 0; t < n_jobs; t++) {
     const size_t lo = (size_t)t * per, hi = (lo + per < n_lanes) ? lo + per : n_lanes;
     if (lo >= hi) break;
-    jobs[n_jobs].lanes = lanes;
-    jobs[n_jobs].dl = dl;
-    jobs[n_jobs].order = order;
-    jobs[n_jobs].lo = lo;
-    jobs[n_jobs].hi = hi;
-    jobs[n_jobs].filter_only = filter_only;
-    jobs[n_jobs].rc = VS_OK;
-    jobs[n_jobs].bad = 0;
-    n_jobs++;
+    ExpandJob *j = &jobs[made++];
+    j->lanes = lanes;
+    j->dl = dl;
+    j->order = order;
+    j->key = key;
+    j->lo = lo;
+    j->hi = hi;
+    j->filter_only = filter_only;
   }
-  /* the last range runs on this thread; a thread that cannot be started is run here too */
-  for (int t = 0; t + 1 < n_jobs; t++) {
-    if (pthread_create(&th[t], NULL, expand_range, &jobs[t]) != 0) break;
-    started++;
-  }
-  for (int t = started; t < n_jobs; t++) expand_range(&jobs[t]);
-  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+  team_run(team, expand_range, jobs, sizeof(ExpandJob), made);
   /* the failure of the lowest lane: the same answer whatever the thread count and the order */
   int rc = VS_OK;
   size_t bad = (size_t)-1;
+  uint64_t k_or = 0, k_and = ~(uint64_t)0;
   VsBatchStats all;
   stats_init(&all);
-  for (int t = 0; t < n_jobs; t++) {
+  for (int t = 0; t < made; t++) {
     if (jobs[t].rc != VS_OK && jobs[t].bad < bad) {
       rc = jobs[t].rc;
       bad = jobs[t].bad;
     }
     stats_merge(&all, &jobs[t].st);
+    k_or |= jobs[t].key_or;
+    k_and &= jobs[t].key_and;
   }
   if (stats) *stats = all;
+  if (varying) *varying = made ? (k_or ^ k_and) : 0; /* bits of the key that differ somewhere */
+  return rc;
+}
+
+/* stable LSD radix sort of the lane indices by key, 16 bits per pass, passes whose digit is the same in every key
+ * skipped; returns the array that holds the order (a or b) */
+static uint32_t *radix_order(const uint64_t *key, uint64_t varying, size_t n_lanes, uint32_t *a, uint32_t *b, size_t *count)
+{
+  for (size_t l = 0; l < n_lanes; l++) a[l] = (uint32_t)l;
+  for (int shift = 0; shift < 64; shift += 16) {
+    if (!((varying >> shift) & 0xFFFFu)) continue;
+    memset(count, 0, 65537 * sizeof(size_t));
+    for (size_t i = 0; i < n_lanes; i++) count[((key[a[i]] >> shift) & 0xFFFFu) + 1]++;
+    for (size_t d = 0; d < 65536; d++) count[d + 1] += count[d];
+    for (size_t i = 0; i < n_lanes; i++) b[count[(key[a[i]] >> shift) & 0xFFFFu]++] = a[i];
+    uint32_t *sw = a;
+    a = b;
+    b = sw;
+  }
+  return a;
+}
+
+/* The records of a batch in the order the kernels want (source kinds; filter-only: input order), in the workspace's
+ * memory: ONE parallel pass over the lanes makes every record where its lane stands and notes its order key -- the
+ * 27 MB of a 65536-lane batch are read once, by all threads --, and only a batch whose keys differ is sorted (lane
+ * indices, serially: two 16-bit passes for an F0 sweep) and gathered into the second buffer (8 MB, in parallel, out of
+ * the caches).  *dl_out stays valid until the next call on this workspace. */
+int vs_expand_all_ordered_ws(VsPlanWs *ws, const vs_lane *lanes, size_t n_lanes, int filter_only, VsDevLane **dl_out,
+                             int *reordered, VsBatchStats *stats)
+{
+  if (!ws || !lanes || !dl_out || n_lanes == 0) return VS_ERR_ARG;
+  if (reordered) *reordered = 0;
+  const int may_order = !filter_only && n_lanes >= 2 && n_lanes <= 0xFFFFFFFFu;
+  int rc = ws_reserve(ws, n_lanes, 0);
+  if (rc != VS_OK) return rc;
+  if (n_lanes >= VS_TEAM_MIN_LANES && !ws->team) ws->team = team_create(); /* NULL: this thread alone */
+  VsTeam *team = (n_lanes >= VS_TEAM_MIN_LANES) ? ws->team : NULL;
+  uint64_t varying = 0;
+  rc = expand_pass(team, lanes, ws->rec[0], n_lanes, filter_only, NULL, may_order ? ws->key : NULL, &varying, stats);
+  if (rc != VS_OK) return rc;
+  *dl_out = ws->rec[0];
+  if (!may_order || !varying) return VS_OK;
+  rc = ws_reserve(ws, n_lanes, 1);
+  if (rc != VS_OK) return rc;
+  const uint32_t *order = radix_order(ws->key, varying, n_lanes, ws->idx[0], ws->idx[1], ws->count);
+  GatherJob jobs[VS_MAX_JOBS];
+  const int n_jobs = jobs_for(n_lanes, team != NULL);
+  const size_t per = (n_lanes + (size_t)n_jobs - 1) / (size_t)n_jobs;
+  int made = 0;
+  for (int t = 0; t < n_jobs; t++) {
+    const size_t lo = (size_t)t * per, hi = (lo + per < n_lanes) ? lo + per : n_lanes;
+    if (lo >= hi) break;
+    GatherJob *j = &jobs[made++];
+    j->in = ws->rec[0];
+    j->out = ws->rec[1];
+    j->order = order;
+    j->lo = lo;
+    j->hi = hi;
+  }
+  team_run(team, gather_range, jobs, sizeof(GatherJob), made);
+  *dl_out = ws->rec[1];
+  if (reordered) *reordered = 1;
+  return VS_OK;
+}
+
+/* the same into the caller's memory, with a workspace of its own (tests, small tools) */
+static int expand_into(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, int ordered, int *reordered,
+                       VsBatchStats *stats)
+{
+  if (!lanes || !dl) return VS_ERR_ARG;
+  if (reordered) *reordered = 0;
+  if (n_lanes == 0) {
+    if (stats) stats_init(stats);
+    return VS_OK;
+  }
+  if (!ordered) { /* input order: straight into the caller's memory */
+    VsTeam *team = (n_lanes >= VS_TEAM_MIN_LANES) ? team_create() : NULL;
+    const int rc = expand_pass(team, lanes, dl, n_lanes, filter_only, NULL, NULL, NULL, stats);
+    team_destroy(team);
+    return rc;
+  }
+  VsPlanWs *ws = vs_planws_create();
+  if (!ws) return VS_ERR_NOMEM;
+  VsDevLane *out = NULL;
+  const int rc = vs_expand_all_ordered_ws(ws, lanes, n_lanes, filter_only, &out, reordered, stats);
+  if (rc == VS_OK) memcpy(dl, out, n_lanes * sizeof(VsDevLane));
+  vs_planws_destroy(ws);
   return rc;
 }
 
 int vs_expand_all(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only)
 {
-  return expand_with_order(lanes, dl, n_lanes, filter_only, NULL, NULL);
+  return expand_into(lanes, dl, n_lanes, filter_only, 0, NULL, NULL);
 }
 
 int vs_expand_all_stats(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int filter_only, VsBatchStats *stats)
 {
-  return expand_with_order(lanes, dl, n_lanes, filter_only, NULL, stats);
+  return expand_into(lanes, dl, n_lanes, filter_only, 0, NULL, stats);
 }
 
 /* The order the kernels want -- wavefronts are formed from lanes with similar periods: by (P, T2, jitter / shimmer /
  * noise on or off), stable -- found BEFORE the records are made, from a 64-bit key per lane that restates the three
- * fields (flowgen_shimmer.c:244, :317 and the option flags), so that the expansion writes every record straight into
- * its place: no second pass over 19 MB of records (BASELINE config 5: the merge sort + gather of round 4 took longer
- * than the expansion itself).  LSD radix sort of the lane indices, 16 bits per pass, passes whose digit is the same
- * in every key skipped (a homogeneous batch: none run, and *order_out stays NULL = input order). */
+ * fields (flowgen_shimmer.c:244, :317 and the option flags) -- what record_order_key() reads off a finished record.
+ * vs_kernel_order() answers from the lanes alone (tests hold the plan's order against it); the plan itself takes the
+ * keys from the records it has just made (vs_expand_all_ordered_ws).  LSD radix sort of the lane indices, 16 bits per
+ * pass, passes whose digit is the same in every key skipped (a homogeneous batch: none run, and *order_out stays
+ * NULL = input order). */
 static uint64_t lane_order_key(const vs_lane *lane)
 {
   uint64_t P = 0, T2 = 0;
@@ -423,13 +710,7 @@ int vs_kernel_order(const vs_lane *lanes, size_t n_lanes, uint32_t **order_out)
 
 int vs_expand_all_ordered(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int *reordered, VsBatchStats *stats)
 {
-  uint32_t *order = NULL;
-  int rc = vs_kernel_order(lanes, n_lanes, &order);
-  if (rc != VS_OK) return rc;
-  if (reordered) *reordered = order != NULL;
-  rc = expand_with_order(lanes, dl, n_lanes, 0, order, stats);
-  free(order);
-  return rc;
+  return expand_into(lanes, dl, n_lanes, 0, 1, reordered, stats);
 }
 
 /* mixed rings: group indices by longest period, descending (ties: lower index first).  A merge sort on the index

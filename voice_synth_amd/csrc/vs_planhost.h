@@ -47,6 +47,14 @@ int vs_expand_all_stats(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int
  * record i comes from (vs_kernel_order), vs_expand_all_ordered does both */
 int vs_kernel_order(const vs_lane *lanes, size_t n_lanes, uint32_t **order);
 int vs_expand_all_ordered(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, int *reordered, VsBatchStats *stats);
+/* What plan creation keeps between calls (one per context): up to 16 worker threads that sleep between plans, the
+ * record buffers, keys and sort arrays.  vs_expand_all_ordered_ws makes the records of a batch in it -- source kinds in
+ * kernel order, filter-only in input order -- and *dl points into the workspace until the next call. */
+typedef struct VsPlanWs VsPlanWs;
+VsPlanWs *vs_planws_create(void);
+void vs_planws_destroy(VsPlanWs *ws);
+int vs_expand_all_ordered_ws(VsPlanWs *ws, const vs_lane *lanes, size_t n_lanes, int filter_only, VsDevLane **dl,
+                             int *reordered, VsBatchStats *stats);
 void vs_cos_row(int T2, double *row);
 /* ring capacity (slots per utterance) and super-step threshold for periods up to tmax */
 int vs_ring_policy_for(int group_lanes, int tmax, int cap, int *slots, int *ready_min, int request, double depth);
