@@ -33,6 +33,11 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
                  launch the same plan twice;
   other_arith  : the other arithmetic contract (fma when the run is exact), HIP events around each of
                  10 launches after 3 warm-ups, outside the timed region;
+  row_pitch_ab : the PCM buffer is the caller's, [utterance][row pitch]; the timed region writes rows at the pitch
+                 vs_row_pitch() names (16064 samples for rows of 16000; --dense-rows: rows only rounded up to 16 bytes),
+                 and this block launches the same plan with both pitches in turn -- both arithmetic modes, 10 launches
+                 with HIP events each, outside the timed region: what the caller's choice is worth
+                 (profiles/r05_row_pitch.txt);
   config4      : N > 1 only -- BASELINE.json's configuration for the node: 262144 utterances x 44100
                  samples (22.05 kHz, 2 s) cut over the N ranks; `value` (PCM left sharded),
                  `roofline_per_gpu`, and `value_with_gather` / `gather`: the same synthesis in chunks of
@@ -80,6 +85,7 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
     ap.add_argument("--arith", choices=["exact", "fma"], default="exact")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense-rows", action="store_true", help="PCM rows only rounded up to 16 bytes instead of the pitch vs_row_pitch() names")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the configs 2 / 4-shard / 5 launches behind the timed region")
     ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the config-4 block (262144 x 44100 over the ranks)")
@@ -342,7 +348,7 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
     specs, fs, dur, label = configs.config_specs(cfg_i, n_lanes, lane0=0)
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
-    pitch = (ns + 7) & ~7
+    pitch = vs.row_pitch(ns)
     plan = eng.plan(lanes, ns)
     out = torch.empty((n_lanes, pitch), dtype=torch.int16, device=dev)
     recs = []
@@ -363,6 +369,7 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
             ms = sorted(a.elapsed_time(b) for a, b in ev)
             avg = sum(ms) / len(ms)
             recs.append({"workload": label, "baseline_config_index": cfg_i - 1, "utterances": n_lanes, "samples_per_utterance": ns,
+                         "row_pitch_samples": pitch,
                          "arith": "exact" if ar == vs.VS_ARITH_EXACT else "fma",
                          "kernel": plan.kernel_name(vs.VS_KIND_SYNTH), "launches": launches,
                          "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(ms[0], 4),
@@ -469,7 +476,11 @@ def main():
     specs, fs, dur, label = configs.config_specs(args.config, per_gpu, lane0=lane0)
     lanes, d = vs.lanes_from_specs(specs)
     n_samples = vs.num_samples(fs, d)
-    pitch = (n_samples + 7) & ~7
+    # the PCM buffer is the caller's: rows of n_samples at the pitch vs_row_pitch() names (include/voice_synth.h: a whole
+    # number of 128-byte lines, 3 mod 4 -- 16064 samples for 16000), or, --dense-rows, only rounded up to 16 bytes.  The
+    # line says which (config.row_pitch_samples) and carries the other one's launch time (`dense_rows` / `pitched_rows`).
+    dense_pitch = (n_samples + 7) & ~7
+    pitch = dense_pitch if args.dense_rows else vs.row_pitch(n_samples)
 
     arith = vs.VS_ARITH_EXACT if args.arith == "exact" else vs.VS_ARITH_FMA
     stream = torch.cuda.current_stream(dev)
@@ -491,7 +502,9 @@ def main():
     # (HW_ID probe), and the plan says whether it had to fall back to two roles
     c12, c8 = eng.simd_dealing()
     wave_to_simd = dict(plan.roles(), cyclic_12_wavefronts=c12, cyclic_8_wavefronts=c8)
-    out = torch.empty((per_gpu, pitch), dtype=torch.int16, device=dev)
+    out = torch.empty((per_gpu, max(pitch, vs.row_pitch(n_samples))), dtype=torch.int16, device=dev)
+    if out.shape[1] != pitch:
+        out = out.view(-1)[: per_gpu * pitch].view(per_gpu, pitch)   # --dense-rows: the same allocation, rows at the dense pitch
 
     def launch():
         plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)
@@ -582,6 +595,35 @@ def main():
     plan.status()
     other_kern = sorted(a.elapsed_time(b) for a, b in oev)
     other_ms = sum(other_kern) / len(other_kern)
+
+    # ---- what the row pitch is worth, outside the timed region: the same plan into the same allocation with rows at the
+    # pitch vs_row_pitch() names and with dense rows (16-byte multiples), launches of the two INTERLEAVED (the chip's clock
+    # drifts over a run: only launches that alternate can be compared), both arithmetic modes, 3 warm-ups + 10 launches
+    # with HIP events each (profiles/r05_row_pitch.txt, tools/pitch_probe.py).
+    pitch_ab = {"how": "launches alternate between the two pitches; HIP events around each; outside the timed region"}
+    ab_pitches = (("pitched", vs.row_pitch(n_samples)), ("dense", dense_pitch))
+    for a_mode, a_name in ((vs.VS_ARITH_EXACT, "exact"), (vs.VS_ARITH_FMA, "fma")):
+        eng.set_arith(a_mode)
+        for _ in range(3):
+            for _, p_ in ab_pitches:
+                plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=p_)
+        torch.cuda.synchronize(dev)
+        aev = {k_: [] for k_, _ in ab_pitches}
+        for _ in range(10):
+            for k_, p_ in ab_pitches:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=p_)
+                b.record(stream)
+                aev[k_].append((a, b))
+        torch.cuda.synchronize(dev)
+        plan.status()
+        for k_, p_ in ab_pitches:
+            a_ms = sorted(a.elapsed_time(b) for a, b in aev[k_])
+            pitch_ab.setdefault(k_, {"row_pitch_samples": p_})[a_name] = {
+                "kernel_ms_avg": round(sum(a_ms) / len(a_ms), 4), "kernel_ms_median": round(a_ms[len(a_ms) // 2], 4),
+                "kernel_ms_min": round(a_ms[0], 4),
+                "Msamples/s_per_gpu": round(per_gpu * n_samples / (sum(a_ms) / len(a_ms) * 1e-3) / 1e6, 1)}
     eng.set_arith(arith)
 
     # ---- fresh batches, outside the timed region (N = 1 only): what a caller pays who synthesises NEW utterances -- a plan
@@ -665,6 +707,8 @@ def main():
                 "utterances_per_gpu": per_gpu,
                 "samples_per_utterance": n_samples,
                 "sample_rate_hz": fs,
+                "row_pitch_samples": pitch,
+                "rows": "dense (16-byte multiple)" if args.dense_rows else "vs_row_pitch(): whole 128-byte lines, their number 3 mod 4",
                 "arith": args.arith,
                 "parallelism": "utterances sharded over %d GPU(s), no data-path collective" % world,
             },
@@ -693,6 +737,7 @@ def main():
                             "kernel_ms_median": round(other_kern[len(other_kern) // 2], 4),
                             "kernel_ms_min": round(other_kern[0], 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
+            "row_pitch_ab": pitch_ab,
             "other_configs": other_configs,
             "fresh_batches": fresh,
             "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
@@ -933,7 +978,7 @@ def config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases):
     specs, fs, dur, label = configs.config_specs(4, per, lane0=lo)
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
-    pitch = (ns + 7) & ~7
+    pitch = vs.row_pitch(ns)
     steps = max(2, min(args.steps, 5))
     nbytes = (total - (shard_range(total, 0, world)[1] - shard_range(total, 0, world)[0])) * ns * 2   # into rank 0
     allow = PHASE_DEADLINE_S + nbytes / 1e9       # 60 s + 1 s per GB that has to reach rank 0

@@ -134,6 +134,16 @@ int vs_lane_defaults(vs_lane *lane);
 /* nSamples = (unsigned long) par.fs * par.dur, a FLOAT product (flowgen_shimmer.c:242). */
 int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples);
 
+/* Row pitch (in samples) that suits the kernels' stores for rows of n_samples: a caller who allocates the PCM buffer
+ * [n_lanes][pitch] may pick any pitch >= n_samples, and the choice is worth 2-5 % of a full-chip launch (up to 14 % against
+ * an unlucky one).  Why: a wavefront's store instruction writes 16 bytes into each of 64 rows at the SAME offset, so the
+ * distance between rows decides how those 64 writes spread over the L2's channels -- rows a multiple of 256 bytes apart
+ * (16000 samples: 32000 bytes) use half of them, rows a power of two apart (16384 samples) pile up on a few
+ * (profiles/r05_row_pitch.txt, tools/pitch_probe.py).  Returned: n_samples rounded up to a whole number of 128-byte
+ * lines, that number being 3 (mod 4); rows shorter than 2 KiB are only rounded up to 16 bytes.  Every pitch >= n_samples
+ * remains VALID (vs_plan_launch takes what it is given); this one is the fast one. */
+size_t vs_row_pitch(size_t n_samples);
+
 /* The denominator tables of coefficients(), vowel_new.c:430-633.  A receives 23 doubles. */
 int vs_vowel_coefficients(int vowel, double *A);
 
@@ -258,7 +268,7 @@ void vs_plan_destroy(vs_plan *plan);
 
 /* Launch on the context's stream; returns without waiting for the device.
  *   in_dev   : VS_KIND_FILTER only, int16 [n_lanes][in_pitch] glottal flow (device pointer)
- *   out_dev  : int16 [n_lanes][out_pitch] (device pointer), out_pitch >= n_samples
+ *   out_dev  : int16 [n_lanes][out_pitch] (device pointer), out_pitch >= n_samples (vs_row_pitch() names the fast one)
  *   log_dev  : optional vs_cycle_rec [n_lanes][log_pitch] (device pointer) or NULL
  *   ncyc_dev : optional int32 [n_lanes], cycles generated per lane, or NULL */
 int vs_plan_launch(vs_plan *plan, int kind, const int16_t *in_dev, size_t in_pitch,

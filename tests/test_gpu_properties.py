@@ -350,6 +350,33 @@ def test_corner_parameter_fuzz():
         assert bad == 0, "%d lanes differ (kernel %s)" % (bad, kernel)
 
 
+def test_rows_at_the_recommended_pitch_equal_dense_rows(engine):
+    """the PCM buffer's row pitch is the caller's (vs_row_pitch names the fast one): the same plan into pitched rows and
+    into dense rows gives the same samples, and the bytes between the rows are left alone"""
+    specs, fs, dur, _ = configs.config_specs(3, 4096 + 37)
+    lanes, d = vs.lanes_from_specs(specs)
+    n = 4001   # odd: the last super-step stores sample by sample
+    n_lanes = len(lanes)
+    pitch = vs.row_pitch(n)
+    assert pitch > n and pitch % 64 == 0
+    want = engine.synth(lanes, n)
+    buf = engine.dev_alloc(n_lanes * pitch * 2)
+    try:
+        poison = np.full((n_lanes, pitch), 0x5A5A, dtype=np.int16)
+        engine.dev_upload(buf, poison)
+        plan = engine.plan(lanes, n)
+        try:
+            plan.launch(vs.VS_KIND_SYNTH, buf, out_pitch=pitch)
+            plan.status()
+        finally:
+            plan.close()
+        got = engine.dev_download(buf, (n_lanes, pitch))
+        assert np.array_equal(got[:, :n], want)
+        assert (got[:, n:] == 0x5A5A).all()
+    finally:
+        engine.dev_free(buf)
+
+
 def _is_fast(lane):
     d = vs._ffi.DevLane()
     vs.load().vs_expand_lane(C.byref(lane), 0, C.byref(d))

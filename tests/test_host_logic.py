@@ -215,6 +215,19 @@ def test_cli_usage_text_equals_reference():
         assert ours.stdout == ref.stdout and ours.returncode == ref.returncode == 0
 
 
+def test_row_pitch_rule():
+    """vs_row_pitch: >= n_samples, a 16-byte multiple; rows of 2 KiB and more a whole number of 128-byte lines, that number
+    3 mod 4 (profiles/r05_row_pitch.txt: rows 256-byte multiples or powers of two apart are the slow ones)"""
+    assert vs.row_pitch(16000) == 16064 and vs.row_pitch(44100) == 44224 and vs.row_pitch(16384) == 16576
+    assert vs.row_pitch(1) == 8 and vs.row_pitch(1000) == 1000 and vs.row_pitch(1023) == 1024 and vs.row_pitch(1024) == 1216
+    for n in list(range(1, 5000, 7)) + [2 ** k + d for k in range(10, 31) for d in (-1, 0, 1)]:
+        p = vs.row_pitch(n)
+        assert p >= n and p % 8 == 0 and p - n < 4 * 64 + 64
+        if 2 * n >= 2048:
+            assert (2 * p) % 128 == 0 and (2 * p // 128) % 4 == 3
+    assert vs.row_pitch(2 ** 63) == 2 ** 63   # nothing to round with: the caller's rows as they are
+
+
 def test_expand_lane_pads_a_low_order_set_with_zeros():
     """an explicit set of fewer than 22 taps rides the order-22 kernels: taps behind its order are zeros in its row of
     the plan's tap table (acc - 0*y == acc); rows 0..9 of that table are the reference's ten tables (vw:450-544)"""

@@ -128,6 +128,11 @@ def num_samples(fs, dur):
     return int(n.value)
 
 
+def row_pitch(n_samples):
+    """vs_row_pitch: the row pitch (samples) the kernels' stores like for rows of n_samples"""
+    return int(load().vs_row_pitch(int(n_samples)))
+
+
 def vowel_coefficients(vowel):
     a = (C.c_double * _ffi.VS_NCOEF)()
     v = ord(vowel) if isinstance(vowel, str) else int(vowel)

@@ -161,6 +161,7 @@ _vp = C.c_void_p
 SYMBOLS = {
     "vs_lane_defaults": (C.c_int, [_P(Lane)]),
     "vs_num_samples": (C.c_int, [C.c_int32, C.c_float, _P(C.c_uint64)]),
+    "vs_row_pitch": (C.c_size_t, [C.c_size_t]),
     "vs_vowel_coefficients": (C.c_int, [C.c_int, _P(C.c_double)]),
     "vs_lane_order": (C.c_int, [_P(Lane), _P(C.c_int)]),
     "vs_vowel_name": (C.c_char_p, [C.c_int]),

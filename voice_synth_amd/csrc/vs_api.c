@@ -143,6 +143,7 @@ void vs_ctx_destroy(vs_ctx *ctx)
     (void)hipStreamDestroy(ctx->own_upload);
   }
   vs_planws_destroy(ctx->planws);
+  if (ctx->plan_pin) (void)hipHostFree(ctx->plan_pin);
   free(ctx);
 }
 
@@ -307,6 +308,25 @@ int vs_dev_download(vs_ctx *ctx, void *dst_host, const void *src_dev, size_t byt
   return VS_OK;
 }
 
+/* Page-locked host memory for what a big plan sends to the device.  From pageable memory the runtime copies with a
+ * kernel of its own, and that kernel waits until the chip has room -- i.e. until the launch before it has ENDED, when
+ * that launch fills every CU for its whole duration as the fused kernel does: the plan of batch k + 1 then goes up
+ * behind kernel k instead of next to it (bench.py fresh_batches: upload 1.8 ms instead of 0.3).  From page-locked memory
+ * it is a DMA transfer. */
+static void *plan_pinned_alloc(void *user, size_t bytes)
+{
+  vs_ctx *ctx = (vs_ctx *)user;
+  void *p = NULL;
+  if (hipSetDevice(ctx->device) != hipSuccess) return NULL;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return NULL;
+  return p;
+}
+static void plan_pinned_free(void *user, void *ptr)
+{
+  (void)user;
+  if (ptr) (void)hipHostFree(ptr);
+}
+
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                         int mode, vs_plan **out)
 {
@@ -324,13 +344,17 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   /* the records are made in the context's plan workspace (csrc/vs_planhost.c: worker threads that sleep between plans,
    * record buffers that are kept -- a fresh 8 MB block per plan is two thousand page faults); everything else of this
    * call is released at `done` */
-  if (!ctx->planws) ctx->planws = vs_planws_create();
+  if (!ctx->planws) {
+    ctx->planws = vs_planws_create();
+    vs_planws_set_big_allocator(ctx->planws, plan_pinned_alloc, plan_pinned_free, ctx);
+  }
   if (!ctx->planws) return VS_ERR_NOMEM;
   VsDevLane *dl = NULL;
   double *costab = NULL;   /* the cos rows, one per distinct T2 */
   size_t costab_len = 0, costab_cap = 0;
   int *row_of_T2 = NULL;   /* first entry of the row of T2 in costab, -1: not built yet */
   double *awide = NULL;    /* wide plans: the 40 taps of every lane record, in the records' (sorted) order */
+  void *small_tmp = NULL;  /* stand-in for the page-locked staging block when there is none */
   VsGroupSlot *gmap = NULL; /* mixed rings: which group, which ring depth, which LDS region per (workgroup, slot) */
   vs_plan *p = NULL;
   const double t_host0 = vs_now_ms();
@@ -644,6 +668,10 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   const size_t zc_lanes = n_lanes * sizeof(VsDevLane), zc_cos = (costab_len + 1) * sizeof(double);
   const size_t zc_off_cos = (zc_lanes + 63) & ~(size_t)63, zc_off_err = (zc_off_cos + zc_cos + 63) & ~(size_t)63;
   const size_t zc_off_wide = zc_off_err + 64, zc_wide = wide ? n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double) : 0;
+  /* plans that copy: [cos rows + taps | mixed-rings table | error word], at least VS_SMALL_BLOCK_MIN bytes */
+  const size_t small_gmap_bytes = gmap ? n_wg_mixed * 4 * sizeof(VsGroupSlot) : 0;
+  const size_t small_off_gmap = (zc_cos + 63) & ~(size_t)63, small_off_err = (small_off_gmap + small_gmap_bytes + 63) & ~(size_t)63;
+  const size_t small_alloc = (small_off_err + 64 > VS_SMALL_BLOCK_MIN) ? small_off_err + 64 : VS_SMALL_BLOCK_MIN;
   if (zero_copy) {
     /* one pinned, device-mapped host block: the CPU writes the records, the kernel reads them over PCIe (a few
      * hundred bytes per utterance, once), the error word is read back by the CPU -- no copy engine involved */
@@ -665,13 +693,22 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     }
   } else {
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_costab, (costab_len + 1) * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_err, sizeof(int));
+    /* the small parts -- cos rows + tap table, the mixed-rings table, the error word -- share ONE device block that is
+     * never smaller than VS_SMALL_BLOCK_MIN and goes up in ONE copy: the runtime moves copies of up to 16 KiB with a
+     * kernel of its own, and that kernel waits until the chip has room, i.e. until a fused launch that is running has
+     * ENDED (it fills every CU for its whole duration), while a copy of 64 KiB is a DMA transfer that runs next to it --
+     * 0.03 ms instead of 2.2 behind a launch (tools/overlap_probe.py, profiles/r05_plan_cost.txt) */
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_small, small_alloc);
+    if (e == hipSuccess) {
+      p->d_costab = (double *)p->d_small;
+      p->d_err = (int *)(p->d_small + small_off_err);
+      if (gmap) p->d_group_map = (VsGroupSlot *)(p->d_small + small_off_gmap);
+    }
     if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
     if (e == hipSuccess) p->d_taps = p->d_costab + taps_off;
   }
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
-  if (e == hipSuccess && gmap) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
+  if (e == hipSuccess && gmap && zero_copy) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
   if (e == hipSuccess && p->opow_pitch)
     e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
   if (e == hipSuccess && wide && !filter_only) {
@@ -698,14 +735,29 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (!zero_copy) {
     if (e == hipSuccess && wide)
       e = hipMemcpyAsync(p->d_awide, awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double), hipMemcpyHostToDevice, up);
-    static const int zero_word = 0; /* a copy, not hipMemsetAsync: a process's first memset loads the runtime's fill kernel (20 ms) */
-    if (e == hipSuccess) e = hipMemcpyAsync(p->d_err, &zero_word, sizeof(int), hipMemcpyHostToDevice, up);
+    /* (the error word is zeroed by the copy, not by hipMemsetAsync: a process's first memset loads the runtime's fill kernel, 20 ms) */
+    void *small_src = NULL;
+    if (e == hipSuccess) {
+      if (ctx->plan_pin_bytes < small_alloc) {
+        if (ctx->plan_pin) (void)hipHostFree(ctx->plan_pin);
+        ctx->plan_pin = NULL;
+        ctx->plan_pin_bytes = 0;
+        if (hipHostMalloc(&ctx->plan_pin, 2 * small_alloc, hipHostMallocDefault) == hipSuccess) ctx->plan_pin_bytes = 2 * small_alloc;
+        else ctx->plan_pin = NULL;
+      }
+      small_src = ctx->plan_pin;
+      if (!small_src) small_src = small_tmp = calloc(1, small_alloc); /* no page-locked memory: a pageable block of the same size */
+      if (!small_src) e = hipErrorOutOfMemory;
+    }
+    if (e == hipSuccess) {
+      char *blk = (char *)small_src;
+      if (costab_len) memcpy(blk, costab, costab_len * sizeof(double));
+      if (small_gmap_bytes) memcpy(blk + small_off_gmap, gmap, small_gmap_bytes);
+      memset(blk + small_off_err, 0, 64);
+      e = hipMemcpyAsync(p->d_small, blk, small_alloc, hipMemcpyHostToDevice, up);
+    }
     if (e == hipSuccess)
       e = hipMemcpyAsync(p->d_lanes, dl, n_lanes * sizeof(VsDevLane), hipMemcpyHostToDevice, up);
-    if (e == hipSuccess && costab_len)
-      e = hipMemcpyAsync(p->d_costab, costab, costab_len * sizeof(double), hipMemcpyHostToDevice, up);
-    if (e == hipSuccess && gmap)
-      e = hipMemcpyAsync(p->d_group_map, gmap, n_wg_mixed * 4 * sizeof(VsGroupSlot), hipMemcpyHostToDevice, up);
     if (e == hipSuccess) e = hipStreamSynchronize(up);
   }
   if (e != hipSuccess) {
@@ -725,6 +777,7 @@ done:
   free(row_of_T2);
   free(awide);
   free(gmap);
+  free(small_tmp);
   return rc;
 }
 
@@ -742,15 +795,14 @@ void vs_plan_destroy(vs_plan *p)
     (void)hipHostFree(p->zc_host); /* records, cos rows, error word and wide taps of a zero-copy plan */
   } else {
     if (p->d_lanes) (void)hipFree(p->d_lanes);
-    if (p->d_costab) (void)hipFree(p->d_costab);
-    if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_small) (void)hipFree(p->d_small); /* cos rows + taps, the mixed-rings table, the error word */
     if (p->d_awide) (void)hipFree(p->d_awide);
   }
   if (p->d_sink) (void)hipFree(p->d_sink);
   if (p->d_seeds) (void)hipFree(p->d_seeds);
   if (p->h_seeds) (void)hipHostFree(p->h_seeds);
   if (p->seeds_copied) (void)hipEventDestroy(p->seeds_copied);
-  if (p->d_group_map) (void)hipFree(p->d_group_map);
+  if (p->d_group_map && !p->d_small) (void)hipFree(p->d_group_map); /* (inside d_small when the plan copies) */
   if (p->d_opow) (void)hipFree(p->d_opow);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   free(p);

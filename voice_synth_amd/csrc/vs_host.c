@@ -75,6 +75,17 @@ int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples)
   return VS_OK;
 }
 
+/* the row pitch the kernels' stores like (include/voice_synth.h; measured: profiles/r05_row_pitch.txt) */
+size_t vs_row_pitch(size_t n_samples)
+{
+  if (n_samples > ((size_t)-1) / 4) return n_samples;   /* no room to round: the caller's rows as they are */
+  const size_t bytes = n_samples * sizeof(int16_t);
+  if (bytes < 2048) return (n_samples + 7) & ~(size_t)7; /* short rows: 16-byte alignment only */
+  size_t lines = (bytes + 127) / 128;
+  while ((lines & 3) != 3) lines++;
+  return lines * (128 / sizeof(int16_t));
+}
+
 /* taps of the lane's filter: 22 for the tables (vowel_new.c:172), vs_lane.order for an explicit set */
 int vs_lane_order(const vs_lane *lane, int *order)
 {

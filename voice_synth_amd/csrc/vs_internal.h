@@ -53,6 +53,8 @@ struct vs_ctx {
   int cu_count;
   vs_tuning tuning; /* all zero = the library's own choices */
   VsPool pool;
+  void *plan_pin;          /* page-locked host block the small parts of a plan go up from (cos rows + taps, group table, the zero word) */
+  size_t plan_pin_bytes;
   struct VsPlanWs *planws; /* plan creation's worker threads and host buffers between calls (csrc/vs_planhost.c; a context is used by one thread at a time) */
   int copy_warm;          /* the runtime's copy path has been set up (vs_copy_path_warm) */
   double copy_warm_ms;    /* ... and what that cost */
@@ -64,10 +66,15 @@ struct vs_ctx {
   unsigned simd_odd_wgs;  /* workgroups of the probe that were dealt differently (selftest counter [6]) */
 };
 
+/* the smallest host-to-device copy the runtime hands to a DMA engine instead of a copy kernel (measured: 16 KiB kernel,
+ * 64 KiB DMA; tools/overlap_probe.py) */
+#define VS_SMALL_BLOCK_MIN ((size_t)65536)
+
 struct vs_plan {
   vs_ctx *ctx;
   size_t n_lanes, n_samples;
   VsDevLane *d_lanes;
+  char *d_small;     /* plans that copy: ONE device block for cos rows + taps, the mixed-rings table and the error word (d_costab, d_group_map, d_err point into it) */
   double *d_costab;
   double *d_taps;    /* the tap table: [rows][22] (rows 0..9 the ten tables, then the lanes' own sets) */
   int ring_slots;

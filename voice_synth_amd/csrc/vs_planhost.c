@@ -381,6 +381,10 @@ struct VsPlanWs {
   VsTeam *team;      /* made with the first batch of VS_TEAM_MIN_LANES lanes or more */
   VsDevLane *rec[2]; /* the records in input order / in kernel order */
   size_t rec_lanes;  /* lanes either holds */
+  int rec_big;       /* the record buffers came from big_alloc (else malloc) */
+  vs_planws_alloc_fn big_alloc; /* where record buffers of VS_TEAM_MIN_LANES lanes and more come from (NULL: malloc) */
+  vs_planws_free_fn big_free;
+  void *big_user;
   uint64_t *key;     /* the order key of every lane */
   uint32_t *idx[2];  /* radix sort of the lane indices */
   size_t key_lanes, idx_lanes;
@@ -391,12 +395,33 @@ struct VsPlanWs {
 #define VS_MAX_JOBS 64
 
 VsPlanWs *vs_planws_create(void) { return (VsPlanWs *)calloc(1, sizeof(VsPlanWs)); }
+void vs_planws_set_big_allocator(VsPlanWs *ws, vs_planws_alloc_fn alloc, vs_planws_free_fn release, void *user)
+{
+  if (!ws || ws->rec[0] || ws->rec[1]) return; /* only before the first batch */
+  ws->big_alloc = (alloc && release) ? alloc : NULL;
+  ws->big_free = (alloc && release) ? release : NULL;
+  ws->big_user = user;
+}
+static void rec_release(VsPlanWs *ws)
+{
+  for (int b = 0; b < 2; b++) {
+    if (ws->rec[b]) {
+      if (ws->rec_big) ws->big_free(ws->big_user, ws->rec[b]);
+      else free(ws->rec[b]);
+    }
+    ws->rec[b] = NULL;
+  }
+  ws->rec_lanes = 0;
+}
+static VsDevLane *rec_alloc(VsPlanWs *ws, size_t lanes)
+{
+  return (VsDevLane *)(ws->rec_big ? ws->big_alloc(ws->big_user, lanes * sizeof(VsDevLane)) : malloc(lanes * sizeof(VsDevLane)));
+}
 void vs_planws_destroy(VsPlanWs *ws)
 {
   if (!ws) return;
   team_destroy(ws->team);
-  free(ws->rec[0]);
-  free(ws->rec[1]);
+  rec_release(ws);
   free(ws->key);
   free(ws->idx[0]);
   free(ws->idx[1]);
@@ -407,18 +432,17 @@ void vs_planws_destroy(VsPlanWs *ws)
 static int ws_reserve(VsPlanWs *ws, size_t n, int need_order)
 {
   if (ws->rec_lanes < n) {
-    for (int b = 0; b < 2; b++) {
-      free(ws->rec[b]);
-      ws->rec[b] = NULL;
-    }
-    ws->rec_lanes = 0;
-    ws->rec[0] = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+    rec_release(ws);
+    /* big batches: from the context's allocator -- page-locked memory, so that the records' way to the device is a DMA
+     * transfer that runs NEXT TO a kernel instead of a copy kernel that waits for the chip to be free */
+    ws->rec_big = (ws->big_alloc != NULL) && n >= VS_TEAM_MIN_LANES;
+    ws->rec[0] = rec_alloc(ws, n);
     if (!ws->rec[0]) return VS_ERR_NOMEM;
     ws->rec_lanes = n;
   }
   if (need_order) {
     if (!ws->rec[1]) {
-      ws->rec[1] = (VsDevLane *)malloc(ws->rec_lanes * sizeof(VsDevLane));
+      ws->rec[1] = rec_alloc(ws, ws->rec_lanes);
       if (!ws->rec[1]) return VS_ERR_NOMEM;
     }
     if (ws->idx_lanes < n) {

@@ -53,6 +53,11 @@ int vs_expand_all_ordered(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, i
 typedef struct VsPlanWs VsPlanWs;
 VsPlanWs *vs_planws_create(void);
 void vs_planws_destroy(VsPlanWs *ws);
+/* where the record buffers of big batches (8192 lanes and more) come from -- the context hands in page-locked memory, so
+ * that their upload is a DMA transfer that runs next to a kernel; before the first batch only, NULL = malloc */
+typedef void *(*vs_planws_alloc_fn)(void *user, size_t bytes);
+typedef void (*vs_planws_free_fn)(void *user, void *ptr);
+void vs_planws_set_big_allocator(VsPlanWs *ws, vs_planws_alloc_fn alloc, vs_planws_free_fn release, void *user);
 int vs_expand_all_ordered_ws(VsPlanWs *ws, const vs_lane *lanes, size_t n_lanes, int filter_only, VsDevLane **dl,
                              int *reordered, VsBatchStats *stats);
 void vs_cos_row(int T2, double *row);
