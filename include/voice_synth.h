@@ -135,13 +135,13 @@ int vs_lane_defaults(vs_lane *lane);
 int vs_num_samples(int32_t fs, float dur, uint64_t *n_samples);
 
 /* Row pitch (in samples) that suits the kernels' stores for rows of n_samples: a caller who allocates the PCM buffer
- * [n_lanes][pitch] may pick any pitch >= n_samples, and the choice is worth 2-5 % of a full-chip launch (up to 14 % against
- * an unlucky one).  Why: a wavefront's store instruction writes 16 bytes into each of 64 rows at the SAME offset, so the
- * distance between rows decides how those 64 writes spread over the L2's channels -- rows a multiple of 256 bytes apart
- * (16000 samples: 32000 bytes) use half of them, rows a power of two apart (16384 samples) pile up on a few
- * (profiles/r05_row_pitch.txt, tools/pitch_probe.py).  Returned: n_samples rounded up to a whole number of 128-byte
- * lines, that number being 3 (mod 4); rows shorter than 2 KiB are only rounded up to 16 bytes.  Every pitch >= n_samples
- * remains VALID (vs_plan_launch takes what it is given); this one is the fast one. */
+ * [n_lanes][pitch] may pick any pitch >= n_samples, and the choice shows in a full-chip launch -- about 2 % between
+ * dense rows of 16000 samples and this pitch, 10-13 % against rows a power of two apart (16384 or 32768 samples, dense).
+ * Why: a wavefront's store instruction writes 16 bytes into each of 64 rows at the SAME offset, so the distance between
+ * the rows decides how those 64 writes spread over the memory channels (profiles/r05_row_pitch.txt,
+ * tools/pitch_probe.py).  Returned: n_samples rounded up to a whole number of 128-byte lines, that number being
+ * 3 (mod 4); rows shorter than 2 KiB are only rounded up to 16 bytes.  Every pitch >= n_samples remains VALID
+ * (vs_plan_launch takes what it is given); this one avoids the slow ones. */
 size_t vs_row_pitch(size_t n_samples);
 
 /* The denominator tables of coefficients(), vowel_new.c:430-633.  A receives 23 doubles. */
