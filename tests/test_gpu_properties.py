@@ -377,6 +377,42 @@ def test_rows_at_the_recommended_pitch_equal_dense_rows(engine):
         engine.dev_free(buf)
 
 
+def test_a_plan_goes_up_next_to_a_running_launch(engine):
+    """a caller who synthesises NEW utterances makes plan k + 1 while kernel k runs -- and the fused kernel fills every CU
+    for its whole duration, so anything the runtime moves with a kernel of its own (copies of up to 16 KiB) waits for its
+    END.  A plan's upload is two DMA-sized copies (records from page-locked memory; cos rows + taps, group table and error
+    word in one block of >= 64 KiB): it must not take as long as what is left of the launch (profiles/r05_plan_cost.txt:
+    0.25 ms next to the kernel, 1.8 ms when it waited)"""
+    import time
+    specs, fs, dur, _ = configs.config_specs(3, 65536)
+    lanes, d = vs.lanes_from_specs(specs)
+    n = vs.num_samples(fs, d)
+    buf = engine.dev_alloc(65536 * n * 2)
+    first = engine.plan(lanes, n)
+    try:
+        first.launch(vs.VS_KIND_SYNTH, buf)
+        engine.synchronize()
+        uploads = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            first.launch(vs.VS_KIND_SYNTH, buf)          # ~2.6 ms of a full chip
+            nxt = engine.plan(lanes, n)                   # ~1 ms of host work, then the upload: the launch is still running
+            host_ms, upload_ms = nxt.timing()
+            made_ms = (time.perf_counter() - t0) * 1e3
+            engine.synchronize()
+            launch_ms = (time.perf_counter() - t0) * 1e3
+            nxt.close()
+            uploads.append((upload_ms, host_ms, made_ms, launch_ms))
+        first.status()
+        best = min(uploads)
+        assert best[3] > 2.0, uploads                      # the launch did outlast the plan ...
+        assert best[2] < best[3] - 0.3, uploads            # ... which was finished well before it
+        assert best[0] < 1.0, uploads                      # and its upload did not wait for the kernel's end
+    finally:
+        first.close()
+        engine.dev_free(buf)
+
+
 def _is_fast(lane):
     d = vs._ffi.DevLane()
     vs.load().vs_expand_lane(C.byref(lane), 0, C.byref(d))
