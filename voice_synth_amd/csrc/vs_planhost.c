@@ -14,6 +14,7 @@
  */
 #include <math.h>
 #include <pthread.h>
+#include <signal.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
@@ -309,6 +310,10 @@ static void *team_worker(void *arg)
 {
   VsTeam *t = (VsTeam *)arg;
   unsigned seen = 0;
+  /* a library's helper threads take no part in the application's signal handling */
+  sigset_t all;
+  sigfillset(&all);
+  (void)pthread_sigmask(SIG_BLOCK, &all, NULL);
   for (;;) {
     pthread_mutex_lock(&t->mu);
     while (t->gen == seen && !t->stop) pthread_cond_wait(&t->go, &t->mu);

@@ -28,7 +28,7 @@ bool vs_lane_is_wide(const vs_lane *lane);
 int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
 int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
 /* what a plan needs to know about its batch as a whole: gathered by the threads that make the records, so that the
- * plan does not walk 19 MB of them again for every question */
+ * plan does not walk all of them again for every question */
 typedef struct VsBatchStats {
   int max_T2;       /* longest cos row */
   int tmax;         /* longest period any lane's rejection test admits (VsDevLane.tbound) */
