@@ -261,7 +261,13 @@ int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len);
  * on the kernels with 64 utterances per wavefront, up to ~3800 (~4500) on the narrow build of the
  * one-wave kernel (16 utterances per wavefront, slow: vs_plan_kernel_name says which).  An utterance's draw stream is
  * indexed with 32 bits: about one draw per sample, so the sample limit keeps it in range for every
- * setting short of rejection loops that retry thousands of times per cycle. */
+ * setting short of rejection loops that retry thousands of times per cycle.
+ * Cost (65536 utterances: about 1 ms on the host and 0.2 ms of upload, profiles/r05_plan_cost.txt): batches of 8192
+ * utterances and more are expanded by worker threads of the context's own -- up to 15, started with the first such plan,
+ * asleep between plans, signals blocked, ended by vs_ctx_destroy -- into page-locked memory, and go up as DMA transfers
+ * that run next to a launch that is under way: a caller who synthesises NEW utterances makes the plan of batch k + 1
+ * while batch k's kernel runs (for new DRAWS of the same utterances there is vs_plan_reseed).  Like the HIP runtime
+ * under it, a context does not survive fork(). */
 int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                    vs_plan **plan);
 void vs_plan_destroy(vs_plan *plan);
