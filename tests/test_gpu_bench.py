@@ -51,6 +51,7 @@ def test_bench_single_process_small():
     d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["cpu_baseline"]["gpu_rows_checked"] >= 1 and d["cpu_baseline"]["gpu_mismatched_samples"] == 0
+    _check_row_pitch(d, 16064)                               # rows at the pitch vs_row_pitch() names, compared with the oracle
     assert d["other_arith"]["launches"] >= 10 and d["other_arith"]["kernel_ms_min"] <= d["other_arith"]["kernel_ms_median"]
     ref = d["cpu_baseline"].get("reference_as_shipped")
     if ref:                                                  # oracle/_ref travels to the GPU box
@@ -68,6 +69,25 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _check_row_pitch(d, want):
+    assert d["config"]["row_pitch_samples"] == want and d["config"]["samples_per_utterance"] == 16000
+    ab = d["row_pitch_ab"]
+    assert ab["pitched"]["row_pitch_samples"] == 16064 and ab["dense"]["row_pitch_samples"] == 16000
+    for rows in ("pitched", "dense"):
+        for arith in ("exact", "fma"):
+            assert ab[rows][arith]["kernel_ms_avg"] > 0
+
+
+def test_bench_dense_rows():
+    """the PCM buffer's rows are the caller's: at the pitch vs_row_pitch() names by default (test_bench_single_process_small),
+    dense with --dense-rows; the line says which and carries the interleaved comparison of the two either way"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--lanes", "4096", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--no-other-configs", "--dense-rows"]
+    out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    _check_row_pitch(_check(out.stdout.decode().strip().splitlines()[-1], 2), 16000)
 
 
 def test_bench_under_torch_distributed_run():

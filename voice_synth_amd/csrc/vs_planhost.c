@@ -442,6 +442,10 @@ static int ws_reserve(VsPlanWs *ws, size_t n, int need_order)
      * transfer that runs NEXT TO a kernel instead of a copy kernel that waits for the chip to be free */
     ws->rec_big = (ws->big_alloc != NULL) && n >= VS_TEAM_MIN_LANES;
     ws->rec[0] = rec_alloc(ws, n);
+    if (!ws->rec[0] && ws->rec_big) { /* no page-locked memory to be had: ordinary memory (the upload is then staged by the runtime) */
+      ws->rec_big = 0;
+      ws->rec[0] = rec_alloc(ws, n);
+    }
     if (!ws->rec[0]) return VS_ERR_NOMEM;
     ws->rec_lanes = n;
   }
