@@ -189,7 +189,7 @@ int main(int argc, char **argv)
     snprintf(kernel, sizeof(kernel), "vs_synth (chunked, pinned destination)");
     if (pcm) vs_host_free(ctx, pcm);
   } else {
-    const size_t pitch = (n_samples + 7) & ~(size_t)7;
+    const size_t pitch = vs_row_pitch((size_t)n_samples); /* the buffer is ours: the pitch the kernels' stores like */
     vs_plan *plan = NULL;
     void *out = NULL;
     rc = vs_plan_create(ctx, lanes, n_lanes, n_samples, &plan);
@@ -215,9 +215,9 @@ int main(int argc, char **argv)
   const double samples = (double)n_lanes * (double)n_samples;
   printf("{\"metric\": \"synthesised Msamples/s\", \"value\": %.1f, \"unit\": \"Msamples/s\", \"ms_per_step\": %.4f, "
          "\"steps\": %d, \"warmup\": %d, \"utterances\": %zu, \"samples_per_utterance\": %llu, \"arith\": \"%s\", "
-         "\"path\": \"%s\", \"GB_per_s_of_pcm\": %.1f}\n",
+         "\"path\": \"%s\", \"row_pitch_samples\": %zu, \"GB_per_s_of_pcm\": %.1f}\n",
          samples * steps / t / 1e6, t / steps * 1e3, steps, warmup, n_lanes, (unsigned long long)n_samples, arith,
-         kernel, 2.0 * samples * steps / t / 1e9);
+         kernel, host ? (size_t)n_samples : vs_row_pitch((size_t)n_samples), 2.0 * samples * steps / t / 1e9);
   vs_ctx_destroy(ctx);
   free(lanes);
   return 0;
