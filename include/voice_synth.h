@@ -233,9 +233,10 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *tuning);
  * [3] rounding, [4] one-fma noise sample (exhaustive over the draws at 16 widths), [5] two-block
  * Philox with prepared round keys, [6] workgroups of the wave-to-SIMD probe below that were NOT dealt
  * "wavefront w next to wavefront w % 4" (a performance assumption, not a correctness one -- but on the hardware this
- * library is written for it holds, and a chip where it does not is worth a failed self-test).  failures
+ * library is written for it holds, and a chip where it does not is worth a failed self-test), [7] the output-noise sample of vowel -n
+ * (conversion of a draw and the one-instruction rounding, exhaustive over the draws and over every float).  failures
  * (optional) receives VS_SELFTEST_COUNTERS counters; VS_OK if all are zero, else VS_ERR_INTERNAL. */
-#define VS_SELFTEST_COUNTERS 7
+#define VS_SELFTEST_COUNTERS 8
 int vs_ctx_selftest(vs_ctx *ctx, uint64_t *failures);
 /* How the hardware deals the wavefronts of a workgroup to the four SIMDs of a compute unit, read from HW_ID by a
  * one-workgroup-per-CU probe launch (once per context, cached): *cyclic12 / *cyclic8 = 1 if in every probed

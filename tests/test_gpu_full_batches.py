@@ -81,6 +81,78 @@ def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel, mi
     assert bad == 0
 
 
+@pytest.mark.parametrize("index,n,roles", [(3, 65536, 3), (5, 65536 - 219, 3), (4, 32768, 3), (2, 1024, 2)])
+def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
+    """vowel -n (vowel_new.c:302-324) behind the kernels bench.py times: the plan of a batch in which every utterance asks
+    for output noise still takes the wave-specialised kernel of its shape -- the frame powers and the noise are two
+    streaming passes over the finished PCM (vs_out_power_kernel, vs_out_noise_kernel), no longer sums inside a one-wave
+    kernel -- and every sample equals the oracle's: config 3 (16 kHz: frames of 800 samples), config 5's F0 sweep over mixed
+    rings with a ragged last group, config 4's shard (22.05 kHz, 2 s: frames of 1100 samples, rows that are no multiple of
+    8 samples long, a last frame of 100) and config 2's shape (no glottal noise: two roles)"""
+    specs, fs, dur, label = configs.config_specs(index, n, out_noise_db=20)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    plan = engine.plan(lanes, ns)
+    out = engine.dev_alloc(n * ns * 2)
+    try:
+        name = plan.kernel_name(vs.VS_KIND_SYNTH)
+        assert name.startswith("vs_synth_ws_kernel<0, true, %d>" % roles) and name.endswith("+ vs_out_power_kernel + vs_out_noise_kernel"), name
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        engine.synchronize()
+        assert plan.status() == 0
+        got = engine.dev_download(out, (n, ns), np.int16)
+    finally:
+        engine.dev_free(out)
+        plan.close()
+    bad = 0
+    for lo in range(0, n, 8192):
+        hi = min(n, lo + 8192)
+        bad += int((got[lo:hi] != po.synth([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
+    print("%s, one launch of %d utterances: %d of %d samples differ" % (label, n, bad, got.size))
+    assert bad == 0
+
+
+def test_mixed_rings_plan_on_the_one_wave_kernel(engine):
+    """a mixed-rings plan (config 5's F0 sweep, full grid) launched as what does NOT take the wave-specialised kernel: the
+    source-only kind and the per-cycle log run the one-wave kernel with ONE group's LDS -- a ring of the plan's deepest
+    depth + its cos rows, not the four-group sum of a mixed-rings workgroup (which left one wavefront per CU) -- and give
+    the oracle's flow, cycle counts and log"""
+    n = 65536 - 219
+    specs, fs, dur, label = configs.config_specs(5, n)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    plan = engine.plan(lanes, ns)
+    recs_per_lane = 420
+    rec_dt = np.dtype([("S", "<f4"), ("x_pow", "<f4"), ("w_pow", "<f4"), ("T", "<i4")])
+    out = engine.dev_alloc(n * ns * 2)
+    log = engine.dev_alloc(n * recs_per_lane * rec_dt.itemsize)
+    ncyc = engine.dev_alloc(n * 4)
+    try:
+        assert plan.info()["lds_bytes"] > 64 * 1024          # mixed rings: several rings per workgroup
+        assert plan.kernel_name(vs.VS_KIND_SOURCE).startswith("vs_synth_kernel<0, 1,")
+        plan.launch(vs.VS_KIND_SOURCE, out, log_ptr=log, log_pitch=recs_per_lane, ncyc_ptr=ncyc)
+        engine.synchronize()
+        assert plan.status() == 0
+        flow = engine.dev_download(out, (n, ns), np.int16)
+        recs = engine.dev_download(log, (n, recs_per_lane), rec_dt)
+        counts = engine.dev_download(ncyc, (n,), np.int32)
+    finally:
+        engine.dev_free(out)
+        engine.dev_free(log)
+        engine.dev_free(ncyc)
+        plan.close()
+    bad = 0
+    for lo in range(0, n, 8192):
+        hi = min(n, lo + 8192)
+        bad += int((flow[lo:hi] != po.source([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
+    assert bad == 0
+    for l in list(range(0, n, 4099)) + [n - 1]:
+        _, want_recs, want_n, _ = po.source_one(lanes[l], ns, max_recs=recs_per_lane)
+        assert counts[l] == want_n
+        for field in ("T", "S", "x_pow", "w_pow"):
+            assert np.array_equal(recs[l, :want_n][field], want_recs[field]), (l, field)
+
+
 def test_full_grid_of_random_utterances_over_mixed_rings():
     """one launch of ~40000 random utterances (F0 60-400 Hz, every option drawn at random, most with glottal noise): a
     full grid whose groups differ in period, i.e. the mixed-rings plan -- groups from across the period range share a

@@ -1,4 +1,5 @@
-"""Quick look at kernel time (wall clock around launch+sync); bench.py is the real harness."""
+"""Quick look at kernel time (wall clock around launch+sync); bench.py is the real harness.
+   tools/quick_bench.py [config] [lanes] [reps]      QB_ONOISE=<dB>: every utterance with "vowel -n <dB>" as well"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +10,8 @@ def main():
     index = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    specs, fs, dur, label = configs.config_specs(index, n)
+    onoise = os.environ.get("QB_ONOISE")
+    specs, fs, dur, label = configs.config_specs(index, n, out_noise_db=float(onoise) if onoise else None)
     t0 = time.time()
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
@@ -18,7 +20,7 @@ def main():
     print(eng.device_info(), flush=True)
     t0 = time.time()
     plan = eng.plan(lanes, ns)
-    print("plan create %.3fs" % (time.time() - t0), plan.info(), flush=True)
+    print("plan create %.3fs" % (time.time() - t0), plan.info(), plan.kernel_name(vs.VS_KIND_SYNTH), flush=True)
     out = eng.dev_alloc(n * ns * 2)
     for arith, name in ((vs.VS_ARITH_EXACT, "exact"), (vs.VS_ARITH_FMA, "fma")):
         eng.set_arith(arith)

@@ -195,8 +195,8 @@ class Engine:
         check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
 
     def selftest(self):
-        """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2, wave-to-SIMD dealing] failure counts)"""
-        f = (C.c_uint64 * 7)()
+        """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2, wave-to-SIMD dealing, output-noise sample] failure counts)"""
+        f = (C.c_uint64 * 8)()
         rc = self._lib.vs_ctx_selftest(self._ctx, f)
         return rc, [int(v) for v in f]
 

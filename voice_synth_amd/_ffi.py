@@ -122,7 +122,7 @@ class DevLane(C.Structure):
         ("thr", C.c_int32),
         ("ready_min", C.c_int32),
         ("tap_row", C.c_int32),
-        ("reserved", C.c_int32),
+        ("lframe_magic", C.c_uint32),
     ]
 
 

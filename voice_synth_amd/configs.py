@@ -127,9 +127,11 @@ def config5_blended_lanes(n_lanes, lane0=0, seed0=1):
     return arr, fs, d, label
 
 
-def config_specs(index, n_lanes=None, lane0=0, seed0=1):
+def config_specs(index, n_lanes=None, lane0=0, seed0=1, out_noise_db=None):
     """Returns (specs, fs, dur, label).  specs[i] = (flowgen_args, vowel_args, seed) of lane
-    lane0+i.  n_lanes defaults to the configuration's full batch."""
+    lane0+i.  n_lanes defaults to the configuration's full batch.  out_noise_db: every utterance also asks the vowel
+    stage for its own noise, "vowel -n <dB>" (vowel_new.c:302-324) -- not part of any BASELINE
+    configuration, the label says so."""
     full = {1: 1, 2: 1024, 3: 65536, 4: 262144, 5: 65536}[index]
     n = full if n_lanes is None else int(n_lanes)
     lanes = np.arange(lane0, lane0 + n, dtype=np.int64)
@@ -173,6 +175,9 @@ def config_specs(index, n_lanes=None, lane0=0, seed0=1):
         label = "config5: batch 65536 F0 sweep 80-300 Hz, random vowel table + gain, 16 kHz 1 s"
     else:
         raise ValueError("config index 1..5")
+    if out_noise_db is not None:
+        specs = [(fa, list(va) + ["-n", "%g" % out_noise_db], seed) for fa, va, seed in specs]
+        label += " + vowel -n %g" % out_noise_db
     return specs, fs, dur, label
 
 

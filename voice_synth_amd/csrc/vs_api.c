@@ -368,8 +368,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   rc = vs_expand_all_ordered_ws(ctx->planws, lanes, n_lanes, filter_only, &dl, NULL, &st);
   if (rc != VS_OK) goto done;
 
-  /* every lane of a launch with output noise accumulates its frame powers, so the rows of the power table must hold
-   * the lane with the MOST frames (the shortest frame), whether it asks for noise or not */
+  /* vowel -n: one noise width per frame; the rows of that table hold the lane with the MOST frames (the shortest frame) */
   int tmax = st.tmax;
   int min_lframe = st.min_lframe; /* shortest frame of the batch, once any lane asks for output noise */
   const bool any_onoise = st.any_onoise != 0;
@@ -433,8 +432,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   /* Launch shape.  A full chip is 4 x cu_count SIMDs.  The fused kind runs WAVE-SPECIALISED
    * whenever it can: two or three wavefronts per 64 utterances with one job each, coupled through
    * the LDS ring (vs_synth_ws_kernel; which roles and which layout: below, and DESIGN.md section 4.2).
-   * The one-wave kernel remains for the source-only and filter-only kinds, the per-cycle log, the
-   * vowel -n power sums, and rings too long for a group to fit the LDS. */
+   * The one-wave kernel remains for the source-only and filter-only kinds, the per-cycle log and rings too
+   * long for a group to fit the LDS.  (vowel -n is two streaming passes behind whichever kernel wrote the PCM.) */
   const unsigned cus = (unsigned)(ctx->cu_count > 0 ? ctx->cu_count : 256);
   /* Utterances per wavefront: 64 -- unless the longest period of the batch does not fit a 64-column
    * ring (the reference takes any rate but an explicit 22050, flowgen_shimmer.c:535-540, and sizes
@@ -646,9 +645,18 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->ready_min = ready_min;
   p->ltab_entries = ltab_entries;
   p->lds_bytes = gmap ? mixed_lds : lds_bytes;
+  /* what ONE group needs when a plan is launched on the one-wave kernel (source-only kind, the per-cycle log): a ring of
+   * the plan's deepest depth + the worst wavefront's cos rows -- not the four-group sum a mixed-rings workgroup takes */
+  p->lds_one_wave = filter_only ? 0 : (size_t)(slots + VS_TRASH_ROWS) * G * sizeof(int16_t) + (size_t)ltab_entries * sizeof(double);
+  if (p->lds_one_wave > VS_LDS_LIMIT) {
+    free(p);
+    p = NULL;
+    rc = VS_ERR_UNSUPPORTED;
+    goto done;
+  }
   p->ring_slots_min = gmap ? mixed_c_min : slots;
   p->grid = grid;
-  p->opow_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
+  p->ondw_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
@@ -709,8 +717,8 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   }
   if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
   if (e == hipSuccess && gmap && zero_copy) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
-  if (e == hipSuccess && p->opow_pitch)
-    e = hipMalloc((void **)&p->d_opow, n_lanes * (size_t)p->opow_pitch * sizeof(float));
+  if (e == hipSuccess && p->ondw_pitch)
+    e = hipMalloc((void **)&p->d_ondw, n_lanes * (size_t)p->ondw_pitch * sizeof(float));
   if (e == hipSuccess && wide && !filter_only) {
     const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
     if (mode & VS_PLAN_POOL_SCRATCH) {
@@ -803,7 +811,7 @@ void vs_plan_destroy(vs_plan *p)
   if (p->h_seeds) (void)hipHostFree(p->h_seeds);
   if (p->seeds_copied) (void)hipEventDestroy(p->seeds_copied);
   if (p->d_group_map && !p->d_small) (void)hipFree(p->d_group_map); /* (inside d_small when the plan copies) */
-  if (p->d_opow) (void)hipFree(p->d_opow);
+  if (p->d_ondw) (void)hipFree(p->d_ondw);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   free(p);
 }
@@ -875,13 +883,17 @@ int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
              p->ctx->arith);
     return VS_OK;
   }
-  const int ws = p->wave_specialised && kind == VS_KIND_SYNTH && !p->d_opow;
+  const int ws = p->wave_specialised && kind == VS_KIND_SYNTH;
   const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
   if (ws) /* both arithmetic contracts have a pre-emphasis-1.0 instantiation of the wave-specialised kernels */
     snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, p->pre1 ? "true" : "false", p->ws_roles);
   else
     snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
              pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");
+  if (p->d_ondw && kind != VS_KIND_SOURCE) { /* vowel -n: the two passes behind it */
+    const size_t used = strlen(buf);
+    snprintf(buf + used, len - used, " + vs_out_power_kernel + vs_out_noise_kernel");
+  }
   return VS_OK;
 }
 
@@ -938,8 +950,8 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   a.diag = p->d_diag;
   a.err = p->d_err;
   a.sink = p->d_sink;
-  a.opow = (kind == VS_KIND_SOURCE) ? NULL : p->d_opow;
-  a.opow_pitch = p->opow_pitch;
+  a.ondw = (kind == VS_KIND_SOURCE) ? NULL : p->d_ondw;
+  a.ondw_pitch = p->ondw_pitch;
   a.ws_pairs = p->ws_pairs;
   a.ws_roles = p->ws_roles;
   a.ws_layout = p->ws_layout;
@@ -984,10 +996,10 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
       VsKernelArgs src = a;
       src.out = p->d_flow;
       src.out_pitch = (long)p->flow_pitch;
-      src.opow = NULL;
+      src.ondw = NULL;
       src.vec_ok = 1; /* rows of the plan's own buffer start 16-byte aligned */
       VS_HIP(ctx, vs_launch_kernel(ctx->arith, VS_KIND_SOURCE, src.log != NULL, false, false, &src, p->grid,
-                                   p->lds_bytes, ctx->stream));
+                                   p->lds_one_wave, ctx->stream));
       a.in = p->d_flow;
       a.in_pitch = (long)p->flow_pitch;
       a.log = NULL;
@@ -995,11 +1007,13 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
     }
     VS_HIP(ctx, vs_launch_filter_wide(ctx->arith, &a, p->grid, ctx->stream));
   } else {
-    VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != NULL,
-                                 p->wave_specialised != 0 && a.opow == NULL, p->pre1 != 0, &a, p->grid,
-                                 p->lds_bytes, ctx->stream));
+    /* (the launcher takes the wave-specialised kernels for the fused kind without a log only) */
+    const int ws = p->wave_specialised != 0 && kind == VS_KIND_SYNTH && a.log == NULL;
+    VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != NULL, ws != 0, p->pre1 != 0, &a, p->grid,
+                                 ws ? p->lds_bytes : p->lds_one_wave, ctx->stream));
   }
-  if (a.opow) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream)); /* vowel -n, second half */
+  /* vowel -n (vowel_new.c:302-324): two streaming passes over the finished PCM -- every frame's power, then the noise */
+  if (a.ondw) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream));
   return VS_OK;
 }
 

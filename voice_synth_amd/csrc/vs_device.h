@@ -61,7 +61,7 @@ typedef struct VsDevLane {
   int32_t thr;        /* ceil(par.DC) as an integer: for an integer x, (float)x < par.DC  <=>  x < thr   (fg:320, 329) */
   int32_t ready_min;  /* super-step threshold of this lane's 64-utterance group (the same in all its lanes): ready lanes * 64 >= live lanes * ready_min */
   int32_t tap_row;    /* row of A[1..22] in the plan's tap table (vowel_new.c:279-281); from vs_expand_lane: 0..9 = a table, -1 = a set of the lane's own (the plan gives it a row) */
-  int32_t reserved;
+  uint32_t lframe_magic; /* i / Lframe == umulhi(i, lframe_magic) >> (ceil(log2(Lframe)) - 1) for 0 <= i < 2^31 (vs_lframe_magic) */
 } VsDevLane;
 
 /* Wave-specialised launches whose groups differ in period (an F0 sweep): one record per (workgroup, slot) -- which
@@ -94,8 +94,8 @@ typedef struct VsKernelArgs {
   int group_lanes;    /* utterances per wavefront of the one-wave kernel: 64 (or 0), or 16 = the narrow build for long periods */
   int ws_pair_bytes;  /* LDS bytes of one pair: ring + trash row + cos rows + progress words, 16-byte multiple */
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
-  float *opow;        /* vowel -n: per-frame sum of y^2 [n_lanes][opow_pitch], NULL when no lane asks for it */
-  long opow_pitch;
+  float *ondw;        /* vowel -n: NoiseDistWidth of every frame [n_lanes][ondw_pitch] (vs_out_power_kernel -> vs_out_noise_kernel), NULL when no lane asks for it */
+  long ondw_pitch;
   int gen_low;        /* wave-specialised kernel: a lane with fewer buffered samples than this starts a round at once */
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   int spin_limit;     /* polls before a waiting wave gives up and sets err */

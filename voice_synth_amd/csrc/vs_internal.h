@@ -80,13 +80,14 @@ struct vs_plan {
   int ring_slots;
   int ready_min;
   int ltab_entries;
-  size_t lds_bytes;
+  size_t lds_bytes;  /* dynamic LDS of a wave-specialised workgroup's groups (mixed rings: the largest workgroup's sum); one group's ring + cos rows otherwise */
+  size_t lds_one_wave; /* ... of one group on the one-wave kernel (source-only kind, cycle log), whatever the fused launch takes */
   unsigned grid;
   unsigned long long *d_diag; /* VS_DIAG builds: [grid][8] cycle counters, else NULL */
   int *d_err;                 /* spin-limit word of the wave-specialised kernel */
   int16_t *d_sink;            /* VsKernelArgs.sink */
-  float *d_opow;              /* vowel -n: per-frame power sums [n_lanes][opow_pitch], NULL if unused */
-  long opow_pitch;
+  float *d_ondw;              /* vowel -n: NoiseDistWidth per frame [n_lanes][ondw_pitch], NULL if unused */
+  long ondw_pitch;
   int wave_specialised;
   int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
   int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */

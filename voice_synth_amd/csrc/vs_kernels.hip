@@ -155,9 +155,6 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
 #pragma unroll
     for (int k = 0; k < VS_SS / 8; ++k) xpre[k] = *(const vs_u32x4 *)(irow + 8 * k);
   }
-  float fsum = 0.0f; /* vowel -n: running sum of y^2 of the current frame */
-  int fpos = 0, fidx = 0;
-  const int Lframe = L->Lframe;
   int n = 0;     /* this lane's position in its own utterance */
   int rslot = 0; /* ring slot of sample n */
   bool live = valid;
@@ -198,26 +195,6 @@ __global__ void __launch_bounds__(VS_WAVE) vs_synth_kernel(VsKernelArgs args)
       if (KIND != VS_KIND_FILTER) {
         rslot += VS_SS;
         if (rslot >= C) rslot = 0;
-      }
-      if (KIND != VS_KIND_SOURCE && args.opow) {
-        /* vowel -n, first half (vowel_new.c:303-307): aux += (float)y[i]*y[i] over each frame of
-         * Lframe samples, in sample order; the noise itself is added by vs_out_noise_kernel
-         * once the whole frame's power is known */
-        float *prow = args.opow + row * args.opow_pitch;
-#pragma unroll
-        for (int t = 0; t < VS_SS; ++t) {
-          if (n + t < N) {
-            const float f = (float)outv[t];
-            fsum += f * f;
-            fpos += 1;
-            if (fpos == Lframe || n + t == N - 1) {
-              prow[fidx] = fsum;
-              fidx += 1;
-              fsum = 0.0f;
-              fpos = 0;
-            }
-          }
-        }
       }
       n += VS_SS;
       if (n >= N) live = false;
@@ -726,15 +703,19 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
 }
 
 /*
- * vowel -n, second half (reference vowel_new.c:307-320): white noise added to the filtered
- * signal, frame by frame, once each frame's power is known.
- *     sig_power = aux / (float)ni;  NoiseDistWidth = sqrt(12*sig_power/snr);        (float)
- *     noiseval = (1.0*random())/RAND_MAX;  aux = NoiseDistWidth*(noiseval - 0.5);   (float)
+ * vowel -n (reference vowel_new.c:302-324): white noise added to the filtered signal, frame by frame
+ * (Lframe = 800 samples at 16 kHz, 1100 at 22.05 kHz, vw:361-363):
+ *     aux = 0; for every sample of the frame: aux += (float)y[i]*y[i];                (float, in sample order)
+ *     sig_power = aux / (float)ni;  NoiseDistWidth = sqrt(12*sig_power/snr);          (float)
+ *     noiseval = (1.0*random())/RAND_MAX;  aux = NoiseDistWidth*(noiseval - 0.5);     (float <- double)
  *     y[i] = round2int(1.0*y[i] + 1.0*aux);
- * The vowel process draws once per sample, in order, so draw n belongs to sample n: one Philox
- * block serves four consecutive samples and every sample is independent -- a plain streaming
- * kernel, 8 bytes in and out per thread, HBM-bound.  Lframe is a multiple of 100 (milisec1 is
- * even), so four consecutive samples never straddle a frame.
+ * The power of a WHOLE frame stands in front of its first noise sample, so this is two streaming passes over the
+ * finished PCM, behind whatever kernel wrote it (the fused wave-specialised kernels, the one-wave kernel, the wide
+ * filter kernel -- none of them knows about frames):
+ *   vs_out_power_kernel  one thread per (utterance, frame): the sequential float sum, then NoiseDistWidth -> ondw[row][frame];
+ *   vs_out_noise_kernel  one thread per 8 samples: the vowel process draws once per sample, in order, so draw n belongs
+ *                        to sample n -- two Philox blocks per thread, every sample independent.
+ * 2 B/sample read + 4 B/sample read and written, only when asked for.
  */
 /* sqrt(v) correctly rounded to double whatever the last bit of the device sqrt: s is at most
  * one ulp off, the residual r = v - s*s is exact in one fma, and the true root lies beyond
@@ -751,45 +732,187 @@ __device__ __forceinline__ double vs_sqrt_rn(double v)
   return s;
 }
 
-__global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args, long quads_per_lane)
+/* aux += (float)y*y over the 8 samples of 16 bytes of a row, in sample order (vowel_new.c:304-306) */
+__device__ __forceinline__ void vs_power8(const vs_u32x4 v, float &aux)
+{
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = (float)(int)(int16_t)(v[e] & 0xFFFFu), hi = (float)((int)v[e] >> 16);
+    aux += lo * lo;
+    aux += hi * hi;
+  }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) vs_out_power_kernel(VsKernelArgs args)
 {
   const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long l = gid / quads_per_lane;
+  const long l = gid / args.ondw_pitch;
   if (l >= (long)args.n_lanes) return;
-  const long qd = gid - l * quads_per_lane;
+  const int fr = (int)(gid - l * args.ondw_pitch);
   const VsDevLane *__restrict__ L = args.lanes + l;
   const float snr = L->out_snr;
   if (!(snr > 0.0f)) return;
   const int N = args.n_samples;
-  const int i0 = (int)(qd * 4);
+  const int Lframe = L->Lframe;
+  const long f0 = (long)fr * Lframe;
+  if (f0 >= N) return;
+  const int left = N - (int)f0;
+  const int ni = (left < Lframe) ? left : Lframe;
+  const long row = (long)L->row;
+  const int16_t *__restrict__ fp = args.out + row * args.out_pitch + f0;
+  float aux = 0.0f;
+  int i = 0;
+  if (VEC) {
+    /* frames start on even samples (Lframe is a multiple of 100) of rows that start on 4-byte boundaries: 16-byte
+     * loads, eight of them -- one 128-byte line of this thread's frame -- in flight before the first is used, so a
+     * line is asked for once although 64 threads of a wavefront read 64 different frames */
+    const vs_u32x4 *__restrict__ vp = (const vs_u32x4 *)fp;
+    const int nvec = ni >> 3;
+    int c = 0;
+    for (; c + 8 <= nvec; c += 8) {
+      vs_u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = vp[c + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vs_power8(v[j], aux);
+    }
+    for (; c < nvec; ++c) vs_power8(vp[c], aux);
+    i = nvec << 3;
+  }
+  for (; i < ni; ++i) {
+    const float f = (float)fp[i];
+    aux += f * f;
+  }
+  const float sig_power = aux / (float)ni;
+  args.ondw[row * args.ondw_pitch + fr] = (float)vs_sqrt_rn((double)(12.0f * sig_power / snr));
+}
+
+/* One noise sample, literally (vowel_new.c:315-317); r = the draw, what random() returns. */
+__device__ __forceinline__ int vs_onoise_literal(int y, uint32_t r, float ndw)
+{
+  const float noiseval = (float)vs_unit_of_draw(r);
+  const float aux = (float)((double)ndw * ((double)noiseval - 0.5));
+  return vs_round2int(1.0 * (double)y + 1.0 * (double)aux);
+}
+/* ... and as the noise kernel computes it, 19 vector instructions per sample instead of 34 (and the kernel is bound by them:
+ * Philox alone is 9.4).
+ *   noiseval: (float)((1.0*r)/RAND_MAX) is the float next to r/(2^31 - 1) = r*2^-31*(1 + 2^-31 + ...): an integer r of
+ *     up to 31 bits rounded to 24, where the tail only ever decides an exact tie (upwards).  r*inv, inv = RN(1/RAND_MAX),
+ *     is within an ulp of the quotient -- 2^-52 relative, where no integer r lies closer than 2^-31 relative to a point
+ *     that rounds the other way -- so the two correction steps of vs_unit_of_draw() cannot matter behind the
+ *     conversion (device self-test [7]: all 2^31 draws).
+ *   aux: noiseval - 0.5 is exact in double, so RN(NoiseDistWidth * (noiseval - 0.5)) is ONE fused multiply-add,
+ *     fma(NoiseDistWidth, noiseval, -NoiseDistWidth/2): the same exact quantity, rounded once, to double; then to float.
+ *   rounding: y is an integer, so round2int(y + aux) = clamp(y + ceil(aux - 0.5)) for every float aux outside
+ *     (-2^-38, 0): where the double sum y + aux rounds at all (|aux| < 2^-14) it stays strictly between y - 1 and y + 1 on
+ *     aux's side of y, at least 2^-38 - 2^-40 away from the integers the reference's "x + 1" could round up to.  Inside
+ *     that interval round2int has its quirks (x + 1 rounds to an integer: vs_dev_primitives.h).  A nonzero aux is at
+ *     least NoiseDistWidth * 2^-25 in magnitude (the floats next to one half), so a frame whose width is 0 or >= 2^-13
+ *     never meets the interval: the test is per FRAME, not per sample.  ceil(aux - 0.5) = -floor(-aux + 0.5) is ONE
+ *     instruction on gfx950, V_CVT_RPI_I32_F32.
+ *   clamp: widths below 65534 keep |aux| <= 32767, the rounded value fits 16 bits, and two samples are subtracted,
+ *     saturated and lifted from -32768 to the reference's -32767 as a pair (V_CVT_PK_I16_I32, V_PK_SUB_I16 clamp,
+ *     V_PK_MAX_I16) straight from the packed words of the row.
+ * Frames outside [2^-13, 65534) (an SNR beyond ~90 dB, or below 0 dB on a clipped signal: the ABI takes any out_snr > 0)
+ * take the literal form.  Self-test [7]: every float outside (-2^-38, 0) at nine values of y. */
+__device__ __forceinline__ bool vs_onoise_width_is_plain(float ndw) { return (ndw == 0.0f) || (ndw >= 0x1p-13f && ndw < 65534.0f); }
+__device__ __forceinline__ bool vs_onoise_aux_is_plain(float aux)
+{
+  return (__float_as_uint(aux) - 0x80000001u) > 0x2C7FFFFEu; /* not in (-2^-38, -0) */
+}
+/* floor(-aux + 0.5) = -ceil(aux - 0.5) */
+__device__ __forceinline__ int vs_onoise_neg_round(float aux)
+{
+  int r;
+  asm("v_cvt_rpi_i32_f32_e64 %0, -%1" : "=v"(r) : "v"(aux));
+  return r;
+}
+__device__ __forceinline__ int vs_onoise_neg_round_of_draw(uint32_t o, double ndw, double neg_half_ndw)
+{
+  const float noiseval = (float)((double)(o >> 1) * 0x1.00000002p-31);
+  return vs_onoise_neg_round((float)__builtin_fma(ndw, (double)noiseval, neg_half_ndw));
+}
+/* {y.lo - r0, y.hi - r1}, each saturated to int16 and lifted to >= -32767; |r0|, |r1| <= 32767 */
+__device__ __forceinline__ uint32_t vs_onoise_sub2(uint32_t ypair, int r0, int r1)
+{
+  const vs_i16x2 r = __builtin_amdgcn_cvt_pk_i16(r0, r1);
+  uint32_t d;
+  asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(ypair), "v"(__builtin_bit_cast(uint32_t, r)));
+  const vs_i16x2 floor_ = {(short)-32767, (short)-32767};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vs_i16x2, d), floor_));
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args)
+{
+  /* blockIdx.x = the utterance: its key, frame length and row are wave-uniform */
+  const VsDevLane *__restrict__ L = args.lanes + blockIdx.x;
+  const float snr = L->out_snr;
+  if (!(snr > 0.0f)) return;
+  const int N = args.n_samples;
+  const int i0 = (int)((blockIdx.y * 256u + threadIdx.x) * 8u);
   if (i0 >= N) return;
   const long row = (long)L->row;
-  int16_t *__restrict__ orow = args.out + row * args.out_pitch;
-  const int Lframe = L->Lframe;
-  const int fr = i0 / Lframe;
-  const int left = N - fr * Lframe;
-  const int ni = (left < Lframe) ? left : Lframe;
-  const float sig_power = args.opow[row * args.opow_pitch + fr] / (float)ni;
-  const float ndw = (float)vs_sqrt_rn((double)(12.0f * sig_power / snr));
-  uint32_t o[4];
-  vs_philox((uint32_t)qd, L->okey0, L->okey1, o[0], o[1], o[2], o[3]);
+  int16_t *__restrict__ op = args.out + row * args.out_pitch + i0;
+  /* the frames of the two quads (Lframe is a multiple of 4, not of 8): i / Lframe by the record's multiplier */
+  const uint32_t magic = L->lframe_magic;
+  const int sh = 31 - __builtin_clz((unsigned)(L->Lframe - 1)); /* ceil(log2(Lframe)) - 1 */
+  const int fr0 = (int)(__umulhi((uint32_t)i0, magic) >> sh);
+  const int fr1 = (i0 + 4 < N) ? (int)(__umulhi((uint32_t)(i0 + 4), magic) >> sh) : fr0;
+  const float *__restrict__ wrow = args.ondw + row * args.ondw_pitch;
+  const float w0 = wrow[fr0], w1 = wrow[fr1];
+  const bool whole = VEC && (i0 + 8 <= N);
+  vs_u32x4 yp; /* the 8 samples, packed as they lie in the row */
+  if (whole) {
+    yp = *(const vs_u32x4 *)op;
+  } else {
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    if (i0 + w < N) {
-      const float noiseval = (float)vs_unit_of_draw(o[w] >> 1);
-      const float aux = (float)((double)ndw * ((double)noiseval - 0.5));
-      orow[i0 + w] = (int16_t)vs_round2int(1.0 * (double)orow[i0 + w] + 1.0 * (double)aux);
+    for (int e = 0; e < 4; ++e)
+      yp[e] = vs_pack16((i0 + 2 * e < N) ? (int)op[2 * e] : 0, (i0 + 2 * e + 1 < N) ? (int)op[2 * e + 1] : 0);
+  }
+  uint32_t o[8];
+  vs_philox((uint32_t)(i0 >> 2), L->okey0, L->okey1, o[0], o[1], o[2], o[3]);
+  vs_philox((uint32_t)(i0 >> 2) + 1u, L->okey0, L->okey1, o[4], o[5], o[6], o[7]);
+  if (vs_onoise_width_is_plain(w0) && vs_onoise_width_is_plain(w1)) {
+    const double d0 = (double)w0, d1 = (double)w1, h0 = -0.5 * d0, h1 = -0.5 * d1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r0 = vs_onoise_neg_round_of_draw(o[2 * e], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
+      const int r1 = vs_onoise_neg_round_of_draw(o[2 * e + 1], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
+      yp[e] = vs_onoise_sub2(yp[e], r0, r1);
     }
+  } else {
+    int y[8];
+    vs_unpack8(yp, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      yp[e] = vs_clamp_pack16(vs_onoise_literal(y[2 * e], o[2 * e] >> 1, (e < 2) ? w0 : w1),
+                              vs_onoise_literal(y[2 * e + 1], o[2 * e + 1] >> 1, (e < 2) ? w0 : w1));
+  }
+  if (whole) {
+    *(vs_u32x4 *)op = yp;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k < N) op[k] = (int16_t)((k & 1) ? (yp[k >> 1] >> 16) : (yp[k >> 1] & 0xFFFFu));
   }
 }
 
 extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t stream)
 {
-  const long quads = ((long)args->n_samples + 3) / 4;
-  const long total = quads * (long)args->n_lanes;
-  const long blocks = (total + 255) / 256;
-  if (blocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(vs_out_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, *args, quads);
+  if (!args->ondw || args->ondw_pitch <= 0) return hipErrorInvalidValue;
+  const long frames = (long)args->n_lanes * args->ondw_pitch;
+  const long pblocks = (frames + 255) / 256;
+  const long segs = ((long)args->n_samples + 2047) / 2048; /* 256 threads x 8 samples */
+  if (pblocks > 0x7FFFFFFFL || segs > 65535L) return hipErrorInvalidValue;
+  if (args->vec_ok) {
+    hipLaunchKernelGGL(vs_out_power_kernel<true>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(vs_out_noise_kernel<true>, dim3((unsigned)args->n_lanes, (unsigned)segs), dim3(256), 0, stream, *args);
+  } else {
+    hipLaunchKernelGGL(vs_out_power_kernel<false>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(vs_out_noise_kernel<false>, dim3((unsigned)args->n_lanes, (unsigned)segs), dim3(256), 0, stream, *args);
+  }
   return hipGetLastError();
 }
 
@@ -821,10 +944,6 @@ __global__ void __launch_bounds__(VS_WAVE) vs_filter_wide_kernel(VsKernelArgs ar
   const long row = (long)L->row;
   const int16_t *__restrict__ irow = args.in + row * args.in_pitch;
   int16_t *__restrict__ orow = args.out + row * args.out_pitch;
-  float *prow = args.opow ? args.opow + row * args.opow_pitch : nullptr;
-  const int Lframe = L->Lframe;
-  float fsum = 0.0f; /* vowel -n: running sum of y^2 of the current frame (vowel_new.c:303-307) */
-  int fpos = 0, fidx = 0;
   const bool vec = args.vec_ok != 0;
 
   for (int n = 0; n < N; n += VS_WIDE_SS) {
@@ -868,23 +987,6 @@ __global__ void __launch_bounds__(VS_WAVE) vs_filter_wide_kernel(VsKernelArgs ar
         y[t] = acc;                /* the window rotates by renaming, vowel_new.c:287-289 */
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (prow) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int i = n + 8 * g + k;
-          if (i < N) {
-            const float f = (float)outv[k];
-            fsum += f * f;
-            fpos += 1;
-            if (fpos == Lframe || i == N - 1) {
-              prow[fidx] = fsum;
-              fidx += 1;
-              fsum = 0.0f;
-              fpos = 0;
-            }
-          }
-        }
-      }
       if (whole) {
         vs_u32x4 v;
 #pragma unroll
@@ -923,8 +1025,11 @@ extern "C" hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args,
  *   [4] the one-fma noise sample (vs_noise_sample) against the reference's
  *       (short)DC + (short)ceil((r/RAND_MAX)*N - N/2.) for ALL 2^31 draws at 16 (width, DC) pairs,
  *       and for every width 0..VS_NDW_FAST at the edge draws;
- *   [5] vs_philox2 (prepared round keys, two blocks) against vs_philox.
- * bad[k] counts failures of check k.
+ *   [5] vs_philox2 (prepared round keys, two blocks) against vs_philox;
+ *   [7] the output-noise sample (vowel -n, vs_out_noise_kernel): (float)(r*inv) against (float)((1.0*r)/RAND_MAX) for ALL
+ *       2^31 draws, and y - V_CVT_RPI_I32_F32(-aux), clamped, against round2int(1.0*y + 1.0*aux) for EVERY float aux
+ *       (all 2^32 bit patterns but the NaNs and (-2^-38, -0)) at nine y, the packed 16-bit form wherever |aux| <= 32767.
+ * bad[k] counts failures of check k ([6] is the host's: the wave-to-SIMD probe).
  */
 __device__ __forceinline__ int vs_round2int_literal(double x)
 {
@@ -955,7 +1060,7 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
 {
   const unsigned long long tid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const unsigned long long nthreads = (unsigned long long)gridDim.x * 256ull;
-  unsigned long long b0 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+  unsigned long long b0 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b7 = 0;
   for (unsigned long long r = tid; r < (1ull << 31); r += nthreads) {
     const double ref = (1.0 * (double)(uint32_t)r) / 2147483647.0;
     if (vs_unit_of_draw((uint32_t)r) != ref) b0++;
@@ -1037,6 +1142,27 @@ __global__ void __launch_bounds__(256) vs_selftest_kernel(unsigned long long *ba
     for (int w = 0; w < 8; ++w)
       if (o[w] != p[w]) b5++;
   }
+  for (unsigned long long r = tid; r < (1ull << 31); r += nthreads) {
+    const float want = (float)((1.0 * (double)(uint32_t)r) / 2147483647.0);
+    const float got = (float)((double)(uint32_t)r * 0x1.00000002p-31);
+    if (got != want) b7++;
+  }
+  {
+    const int ys[9] = {0, 1, -1, 2, 4096, 16384, 32767, -32767, -32768};
+    for (unsigned long long k = tid; k < (1ull << 32); k += nthreads) {
+      const float aux = __uint_as_float((uint32_t)k);
+      if (aux != aux || !vs_onoise_aux_is_plain(aux)) continue;
+      const int r = vs_onoise_neg_round(aux);
+      const bool narrow = (aux >= -32767.0f) && (aux <= 32767.0f); /* what widths below 65534 give: the packed form */
+      for (int j = 0; j < 9; ++j) {
+        const int want = vs_round2int_literal(1.0 * (double)ys[j] + 1.0 * (double)aux);
+        const long long v = (long long)ys[j] - (long long)r;
+        if ((int)((v > 32767) ? 32767 : ((v < -32767) ? -32767 : v)) != want) b7++;
+        if (narrow && (int)(int16_t)(vs_onoise_sub2((uint32_t)ys[j] & 0xFFFFu, r, 0) & 0xFFFFu) != want) b7++;
+      }
+    }
+  }
+  if (b7) atomicAdd(&bad[7], b7);
   if (b0) atomicAdd(&bad[0], b0);
   if (b2) atomicAdd(&bad[2], b2);
   if (b3) atomicAdd(&bad[3], b3);

@@ -24,6 +24,18 @@
 /* ------------------------------------------------------------------------------------------
  * Host expansion of one lane (no device needed; exported for the CPU-side tests)
  * ---------------------------------------------------------------------------------------- */
+/* The multiplier the output-noise kernel divides a sample index by its frame length with: for d = Lframe >= 2 and
+ * k = ceil(log2 d), m = floor(2^(31+k) / d) + 1 lies in (2^31, 2^32) and floor(i / d) == (i * m) >> (31 + k) for every
+ * 0 <= i < 2^31 (the excess of m over 2^(31+k)/d is at most 1, so the product overshoots i/d by less than
+ * i / 2^(31+k) < 1/d).  0 for frames the vowel stage cannot have (Lframe < 2). */
+uint32_t vs_lframe_magic(int Lframe)
+{
+  if (Lframe < 2) return 0u;
+  int k = 0;
+  while (((uint64_t)1 << k) < (uint64_t)Lframe) k++;
+  return (uint32_t)((((uint64_t)1 << (31 + k)) / (uint64_t)Lframe) + 1u);
+}
+
 /* A[0..40] of the lane's filter: the table or the explicit set, zeros behind its order */
 int vs_lane_taps(const vs_lane *lane, double *A)
 {
@@ -97,6 +109,7 @@ int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
     const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
     const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
     d->Lframe = 50 * milisec1;
+    d->lframe_magic = vs_lframe_magic(d->Lframe);
   }
   if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED; /* fs < 2000: zero-length frames */
   d->okey0 = (uint32_t)lane->out_seed;
@@ -186,6 +199,7 @@ int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d)
     const unsigned long nSamplesPerSec = (unsigned long)lane->fs;
     const int milisec1 = (int)(nSamplesPerSec * 0.001 / 2.0) * 2;
     d->Lframe = 50 * milisec1; /* vowel_new.c:361-363 */
+    d->lframe_magic = vs_lframe_magic(d->Lframe);
   }
   if (lane->out_snr > 0 && d->Lframe <= 0) return VS_ERR_UNSUPPORTED;
   d->okey0 = (uint32_t)lane->out_seed;

@@ -24,6 +24,8 @@ int vs_vowel_by_index(int index);
  * the caller frees it. */
 int vs_tap_table_build(const vs_lane *lanes, VsDevLane *dl, size_t n_lanes, size_t n_custom, double **taps, size_t *rows);
 bool vs_lane_is_wide(const vs_lane *lane);
+/* VsDevLane.lframe_magic: the multiplier behind "sample index / frame length" in vs_out_noise_kernel */
+uint32_t vs_lframe_magic(int Lframe);
 /* one lane -> the record the kernels read (validated); the filter-only form fills what vowel reads */
 int vs_expand_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
 int vs_expand_filter_lane(const vs_lane *lane, int32_t row, VsDevLane *d);
