@@ -335,17 +335,21 @@ def fresh_batches(eng, dev, stream, lanes, n_samples, out, pitch, per_gpu, batch
                    "reseed_*: ONE plan, vs_plan_reseed + launch per batch (same utterances, new draws); wall clock, python in the loop"}
 
 
-def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, warm=5):
+def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, warm=5, out_noise_db=None):
     """One BASELINE configuration outside the timed region: plan, `warm` untimed launches (the chip has idled through the
     plan's host work and comes back on a low clock), then HIP events on the launch stream around each of `launches`
     launches, in both arithmetic contracts.  Returns one record per contract:
-    {workload, kernel, arith, kernel_ms_avg, kernel_ms_min, roofline_frac, ...}."""
+    {workload, kernel, arith, kernel_ms_avg, kernel_ms_min, roofline_frac, ...}.
+    out_noise_db: the same utterances with "vowel -n <dB>" as well (vowel_new.c:302-324): a launch is then
+    the fused kernel (its filter wavefronts take the frame powers along), a scan and the streaming noise pass; the events
+    bracket all three and the record says so (`vowel_n_db`, `bytes_per_sample` 6: 2 written by the fused kernel, 2 read and
+    2 written by the noise pass -- `roofline_frac` stays on the 2 B of the finished sample, like every other row)."""
     import torch
 
     import voice_synth_amd as vs
     from voice_synth_amd import configs
 
-    specs, fs, dur, label = configs.config_specs(cfg_i, n_lanes, lane0=0)
+    specs, fs, dur, label = configs.config_specs(cfg_i, n_lanes, lane0=0, out_noise_db=out_noise_db)
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)
     pitch = vs.row_pitch(ns)
@@ -375,6 +379,9 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
                          "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(ms[0], 4),
                          "Msamples/s": round(n_lanes * ns / (avg * 1e-3) / 1e6, 1),
                          "roofline_frac": round(ALGO_BYTES_PER_SAMPLE * n_lanes * ns / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+            if out_noise_db is not None:
+                recs[-1].update({"vowel_n_db": out_noise_db, "bytes_per_sample": 6,
+                                 "hbm_frac_at_6_bytes": round(6 * n_lanes * ns / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
     finally:
         del out
         plan.close()
@@ -644,9 +651,9 @@ def main():
     other_configs = None
     if world == 1 and rank == 0 and not args.no_other_configs and args.config == 3 and not args.lanes:
         other_configs = []
-        for cfg_i, n_l in ((2, 1024), (4, 262144 // 8), (5, 65536)):
+        for cfg_i, n_l, onoise in ((2, 1024, None), (4, 262144 // 8, None), (5, 65536, None), (3, 65536, 20.0)):
             try:
-                other_configs += measure_config(eng, dev, stream, cfg_i, n_l, arith)
+                other_configs += measure_config(eng, dev, stream, cfg_i, n_l, arith, out_noise_db=onoise)
             except Exception as exc:  # pragma: no cover - reported in the line
                 other_configs.append({"baseline_config_index": cfg_i - 1, "error": "%s: %s" % (type(exc).__name__, exc)})
         eng.set_arith(arith)

@@ -211,6 +211,8 @@ int vs_ctx_last_hip_error(const vs_ctx *ctx);
 #define VS_FAULT_SHARD_PREPARE 3     /* tests: a context that serves a shard of a node fails to prepare its chunks (vs_node_synth_gather) */
 #define VS_FAULT_SHARD_HANDOVER 4    /* tests: ... fails while handing its first chunk over, after the others have started */
 #define VS_FAULT_SIMD_DEALING 5      /* tests: plans behave as if vs_ctx_simd_dealing() had found the wavefronts NOT dealt four at a time */
+#define VS_FAULT_REROUND 6           /* tests: every seventh super-step of the kernels that take vowel -n's frame powers along rounds its results twice, as if
+                                        round2int()'s quirk set had been hit -- the frames concerned must come from the streaming pass instead */
 typedef struct vs_tuning {
   int32_t kernel;     /* VS_KERNEL_* */
   int32_t ring_slots; /* LDS ring capacity per utterance in samples (rounded to 24, clamped to what fits) */

@@ -183,13 +183,21 @@ def test_bench_plain_invocation_propagates_the_watchdog_exit():
 
 def test_bench_line_carries_every_baseline_configuration():
     """the default workload (config 3, full size) with the CPU legs switched off: `other_configs` holds configs 2,
-    4 (one GPU's shard) and 5 in both arithmetic contracts, each with its kernel, time and roofline fraction"""
+    4 (one GPU's shard) and 5 in both arithmetic contracts, each with its kernel, time and roofline fraction -- and config 3
+    once more with the vowel stage's own noise (vowel -n) on every utterance"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, cwd=ROOT, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
     oc = d["other_configs"]
-    assert [(r["baseline_config_index"], r["arith"]) for r in oc] == [(1, "exact"), (1, "fma"), (3, "exact"), (3, "fma"), (4, "exact"), (4, "fma")]
+    assert [(r["baseline_config_index"], r["arith"]) for r in oc] == [(1, "exact"), (1, "fma"), (3, "exact"), (3, "fma"), (4, "exact"), (4, "fma"),
+                                                                      (2, "exact"), (2, "fma")]
+    # the last two: config 3 with "vowel -n 20" on every utterance -- the fused kernel that takes the frame powers along,
+    # the scan, the streaming noise pass: one launch of the plan, bracketed as a whole
+    for r in oc[6:]:
+        assert r["vowel_n_db"] == 20 and r["bytes_per_sample"] == 6
+        assert r["kernel"].startswith("vs_synth_ws_pow_kernel<") and r["kernel"].endswith("+ vs_out_power_fill_kernel + vs_out_noise_kernel")
+        assert r["kernel_ms_avg"] > d["roofline"]["kernel_ms_min"]
     for r in oc:
         assert "error" not in r and r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] >= r["kernel_ms_min"] > 0
         assert abs(r["roofline_frac"] - 2 * r["utterances"] * r["samples_per_utterance"] / (r["kernel_ms_avg"] * 1e-3) / 8e12) < 2e-4

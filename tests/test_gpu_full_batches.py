@@ -84,9 +84,10 @@ def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel, mi
 @pytest.mark.parametrize("index,n,roles", [(3, 65536, 3), (5, 65536 - 219, 3), (4, 32768, 3), (2, 1024, 2)])
 def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
     """vowel -n (vowel_new.c:302-324) behind the kernels bench.py times: the plan of a batch in which every utterance asks
-    for output noise still takes the wave-specialised kernel of its shape -- the frame powers and the noise are two
-    streaming passes over the finished PCM (vs_out_power_kernel, vs_out_noise_kernel), no longer sums inside a one-wave
-    kernel -- and every sample equals the oracle's: config 3 (16 kHz: frames of 800 samples), config 5's F0 sweep over mixed
+    for output noise still takes the wave-specialised kernel of its shape -- its filter wavefronts take the frame powers
+    along (one frame length for the whole batch: vs_synth_ws_pow_kernel), a scan fills in what they left
+    (vs_out_power_fill_kernel), the noise is one streaming pass over the finished PCM (vs_out_noise_kernel) -- and every
+    sample equals the oracle's: config 3 (16 kHz: frames of 800 samples), config 5's F0 sweep over mixed
     rings with a ragged last group, config 4's shard (22.05 kHz, 2 s: frames of 1100 samples, rows that are no multiple of
     8 samples long, a last frame of 100) and config 2's shape (no glottal noise: two roles)"""
     specs, fs, dur, label = configs.config_specs(index, n, out_noise_db=20)
@@ -96,7 +97,7 @@ def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
     out = engine.dev_alloc(n * ns * 2)
     try:
         name = plan.kernel_name(vs.VS_KIND_SYNTH)
-        assert name.startswith("vs_synth_ws_kernel<0, true, %d>" % roles) and name.endswith("+ vs_out_power_kernel + vs_out_noise_kernel"), name
+        assert name == "vs_synth_ws_pow_kernel<0, true, %d> + vs_out_power_fill_kernel + vs_out_noise_kernel" % roles, name
         plan.launch(vs.VS_KIND_SYNTH, out)
         engine.synchronize()
         assert plan.status() == 0
@@ -110,6 +111,62 @@ def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
         bad += int((got[lo:hi] != po.synth([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
     print("%s, one launch of %d utterances: %d of %d samples differ" % (label, n, bad, got.size))
     assert bad == 0
+
+
+@pytest.mark.parametrize("index,n", [(3, 4096), (4, 2048), (3, 65536)])
+def test_output_noise_when_the_fused_kernel_rounds_twice(index, n):
+    """the filter wavefronts that take vowel -n's frame powers along cannot vouch for a frame during which round2int()'s
+    quirk path rounded a super-step again (one chance in 2^32 per sample, or a signal below 2^-54): they mark it and the
+    scan behind the launch (vs_out_power_fill_kernel) sums it from the finished PCM.  Provoked in every seventh super-step
+    (VS_FAULT_REROUND) -- frames that end inside such a super-step, frames that start in one, on both launch shapes and
+    both frame lengths: every sample still equals the oracle's"""
+    specs, fs, dur, label = configs.config_specs(index, n, out_noise_db=17)
+    lanes, d = vs.lanes_from_specs(specs)
+    ns = vs.num_samples(fs, d)
+    eng = vs.Engine(0)
+    eng.set_tuning(fault=vs.VS_FAULT_REROUND)
+    out = None
+    try:
+        plan = eng.plan(lanes, ns)
+        out = eng.dev_alloc(n * ns * 2)
+        assert plan.kernel_name(vs.VS_KIND_SYNTH).startswith("vs_synth_ws_pow_kernel<0, true, 3> + vs_out_power_fill_kernel")
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        eng.synchronize()
+        assert plan.status() == 0
+        got = eng.dev_download(out, (n, ns), np.int16)
+        plan.close()
+    finally:
+        if out:
+            eng.dev_free(out)
+        eng.close()
+    bad = 0
+    for lo in range(0, n, 8192):
+        hi = min(n, lo + 8192)
+        bad += int((got[lo:hi] != po.synth([lanes[i] for i in range(lo, hi)], ns, threads=THREADS)).sum())
+    assert bad == 0
+
+
+def test_output_noise_over_two_frame_lengths_in_one_launch(engine):
+    """a batch whose utterances differ in rate has no frame length the filter wavefronts could share: the plain
+    wave-specialised kernel, and every frame's power from the streaming pass (vs_out_power_kernel)"""
+    lanes = []
+    for l in range(4096):
+        rate = "16000" if l % 3 else "32000"
+        lane, dur = vs.lane_from_cli(["-r", rate, "-d", "1", "-j", "1", "-s", "3", "-n", "25"], ["-v", "aiu1234567"[l % 10], "-g", "3", "-n", "14"], 900 + l)
+        lanes.append(lane)
+    ns = 16000
+    plan = engine.plan(lanes, ns)
+    out = engine.dev_alloc(len(lanes) * ns * 2)
+    try:
+        assert plan.kernel_name(vs.VS_KIND_SYNTH) == "vs_synth_ws_kernel<0, true, 3> + vs_out_power_kernel + vs_out_noise_kernel"
+        plan.launch(vs.VS_KIND_SYNTH, out)
+        engine.synchronize()
+        assert plan.status() == 0
+        got = engine.dev_download(out, (len(lanes), ns), np.int16)
+    finally:
+        engine.dev_free(out)
+        plan.close()
+    assert np.array_equal(got, po.synth(lanes, ns, threads=THREADS))
 
 
 def test_mixed_rings_plan_on_the_one_wave_kernel(engine):

@@ -402,3 +402,32 @@ def test_gather_bookkeeping_ragged_cuts_and_more_shards_than_chunks():
     assert lib.vs_gather_round(10, 2, 2, 4, 0, C.byref(r0), C.byref(rows)) == _ffi.VS_ERR_ARG      # no such shard
     assert lib.vs_gather_round(10, 2, 0, 0, 0, C.byref(r0), C.byref(rows)) == _ffi.VS_ERR_ARG      # no chunk size
     assert lib.vs_gather_round(10, 2, 0, 4, 2 ** 62, C.byref(r0), C.byref(rows)) == 0 and rows.value == 0   # no wrap
+
+
+def test_frame_length_multiplier_divides_every_sample_index():
+    """VsDevLane.lframe_magic (csrc/vs_planhost.c: vs_lframe_magic): the output-noise kernel finds a sample's frame as
+    umulhi(i, magic) >> (ceil(log2(Lframe)) - 1); that must be floor(i / Lframe) for every index a row can have
+    (0 <= i < 2^31) -- checked around every multiple of the frame length near both ends of the range and on a random
+    sample, for the frame lengths of every rate the vowel stage can meet (50 * an even number, vowel_new.c:361-363)"""
+    lib = vs.load()
+    lib.vs_lframe_magic.restype = C.c_uint32
+    lib.vs_lframe_magic.argtypes = [C.c_int]
+    rng = np.random.default_rng(5)
+    lframes = [100, 200, 400, 500, 800, 1100, 2200, 2400, 4800, 9600, 12800, 32700, 100 * 3277, 50 * 2 * 10 ** 6]
+    lframes += [int(x) * 100 for x in rng.integers(1, 20000, size=40)]
+    for d in lframes:
+        m = lib.vs_lframe_magic(d)
+        assert 2 ** 31 < m < 2 ** 32
+        sh = (d - 1).bit_length() - 1
+        top = (2 ** 31 - 1) // d
+        ks = np.unique(np.concatenate([np.arange(0, min(top, 300) + 1), np.arange(max(0, top - 300), top + 1), rng.integers(0, top + 1, size=2000)]))
+        idx = np.unique(np.concatenate([ks * d + o for o in (-2, -1, 0, 1, 2, d // 2)]))
+        idx = idx[(idx >= 0) & (idx < 2 ** 31)].astype(np.uint64)
+        idx = np.concatenate([idx, rng.integers(0, 2 ** 31, size=20000).astype(np.uint64), np.array([2 ** 31 - 1], dtype=np.uint64)])
+        got = ((idx * np.uint64(m)) >> np.uint64(32)) >> np.uint64(sh)
+        assert np.array_equal(got, idx // np.uint64(d)), d
+    assert lib.vs_lframe_magic(0) == 0 and lib.vs_lframe_magic(1) == 0
+    lane, dur = vs.lane_from_cli(["-d", "1"], ["-v", "a", "-n", "20"], 1)
+    rec = _ffi.DevLane()
+    assert lib.vs_expand_lane(C.byref(lane), 0, C.byref(rec)) == 0
+    assert rec.Lframe == 1100 and rec.lframe_magic == lib.vs_lframe_magic(1100)

@@ -49,9 +49,26 @@ def test_two_role_kernels_keep_two_wavefronts_per_simd_without_scratch(recs):
 
 
 def test_no_kernel_of_the_library_uses_scratch(recs):
-    """the one-wave kernels park registers in AGPRs (no scratch traffic); nothing else may spill to memory either"""
+    """the one-wave kernels park registers in AGPRs (no scratch traffic); nothing else may spill to memory either --
+    but for the exact three-role kernels that take vowel -n's frame powers along (next test)"""
     for name, r in recs.items():
-        assert r["scratch"] == 0, (name, r)
+        if not name.startswith("vs_synth_ws_pow_kernel<0"):
+            assert r["scratch"] == 0, (name, r)
+
+
+def test_frame_power_kernels_keep_their_wavefronts(recs):
+    """vs_synth_ws_pow_kernel<*,*,*>: the same kernels with one more running sum per lane.  The exact three-role ones are
+    at 168 registers already and park a few launch constants in scratch (one 8-byte reload per super-step of 24 samples,
+    the rest outside the loop: measured, not free -- DESIGN.md); no instantiation may lose a resident wavefront, and the
+    scratch must stay what it is"""
+    for arith in (0, 1):
+        for pre1 in ("true", "false"):
+            for roles in (2, 3):
+                name = "vs_synth_ws_pow_kernel<%d, %s, %d>" % (arith, pre1, roles)
+                r = recs[name]
+                assert r["occupancy"] >= (3 if roles == 3 else 2), (name, r)
+                assert r.get("agprs", 0) == 0, (name, r)
+                assert r["scratch"] <= (64 if (arith == 0 and roles == 3) else 0), (name, r)
 
 
 def test_superstep_loops_are_in_step_with_the_8_byte_grid():

@@ -33,6 +33,7 @@ from ._ffi import (  # noqa: F401
     VS_FAULT_SHARD_PREPARE,
     VS_FAULT_SHARD_HANDOVER,
     VS_FAULT_SIMD_DEALING,
+    VS_FAULT_REROUND,
     check,
     load,
 )

@@ -152,6 +152,7 @@ VS_FAULT_SHORT_COS_ROWS = 2
 VS_FAULT_SHARD_PREPARE = 3
 VS_FAULT_SHARD_HANDOVER = 4
 VS_FAULT_SIMD_DEALING = 5
+VS_FAULT_REROUND = 6
 VS_DF_FAST = 0x8
 
 

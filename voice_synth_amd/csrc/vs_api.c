@@ -126,7 +126,7 @@ int vs_ctx_set_tuning(vs_ctx *ctx, const vs_tuning *t)
   if (t->gen_low != 0 && t->gen_low < VS_SS) return VS_ERR_ARG;
   if (t->gen_min < 0 || t->gen_min > 64) return VS_ERR_ARG;
   if (t->spin_limit < 0) return VS_ERR_ARG;
-  if (t->fault < 0 || t->fault > VS_FAULT_SIMD_DEALING) return VS_ERR_ARG;
+  if (t->fault < 0 || t->fault > VS_FAULT_REROUND) return VS_ERR_ARG;
   if (t->ws_filter_prio < -1 || t->ws_filter_prio > 3) return VS_ERR_ARG;
   if (t->ws_roles != 0 && t->ws_roles != 2 && t->ws_roles != 3) return VS_ERR_ARG;
   if (t->mixed_rings < -1 || t->mixed_rings > 4096) return VS_ERR_ARG;
@@ -657,6 +657,9 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   p->ring_slots_min = gmap ? mixed_c_min : slots;
   p->grid = grid;
   p->ondw_pitch = min_lframe ? (long)((n_samples + (size_t)min_lframe - 1) / (size_t)min_lframe) : 0;
+  /* one frame length for every lane: the filter wavefronts of the wave-specialised kernels take the frame powers along
+   * (vs_synth_ws_pow_kernel), the streaming pass fills in what they leave */
+  p->pow_lframe = (min_lframe > 0 && wave_specialised && !st.no_lframe && st.max_lframe == min_lframe) ? min_lframe : 0;
   p->wave_specialised = wave_specialised;
   p->ws_pairs = ws_pairs;
   p->ws_roles = ws_roles;
@@ -719,6 +722,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
   if (e == hipSuccess && gmap && zero_copy) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
   if (e == hipSuccess && p->ondw_pitch)
     e = hipMalloc((void **)&p->d_ondw, n_lanes * (size_t)p->ondw_pitch * sizeof(float));
+  if (e == hipSuccess && p->pow_lframe) e = hipMalloc((void **)&p->d_odone, n_lanes * sizeof(int32_t));
   if (e == hipSuccess && wide && !filter_only) {
     const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
     if (mode & VS_PLAN_POOL_SCRATCH) {
@@ -812,6 +816,7 @@ void vs_plan_destroy(vs_plan *p)
   if (p->seeds_copied) (void)hipEventDestroy(p->seeds_copied);
   if (p->d_group_map && !p->d_small) (void)hipFree(p->d_group_map); /* (inside d_small when the plan copies) */
   if (p->d_ondw) (void)hipFree(p->d_ondw);
+  if (p->d_odone) (void)hipFree(p->d_odone);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
   free(p);
 }
@@ -886,13 +891,14 @@ int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
   const int ws = p->wave_specialised && kind == VS_KIND_SYNTH;
   const int pre1 = p->pre1 && p->ctx->arith == VS_ARITH_EXACT && kind != VS_KIND_SOURCE;
   if (ws) /* both arithmetic contracts have a pre-emphasis-1.0 instantiation of the wave-specialised kernels */
-    snprintf(buf, len, "vs_synth_ws_kernel<%d, %s, %d>", p->ctx->arith, p->pre1 ? "true" : "false", p->ws_roles);
+    snprintf(buf, len, "vs_synth_ws_%skernel<%d, %s, %d>", (p->d_ondw && p->pow_lframe) ? "pow_" : "", p->ctx->arith,
+             p->pre1 ? "true" : "false", p->ws_roles);
   else
     snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
              pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");
   if (p->d_ondw && kind != VS_KIND_SOURCE) { /* vowel -n: the two passes behind it */
     const size_t used = strlen(buf);
-    snprintf(buf + used, len - used, " + vs_out_power_kernel + vs_out_noise_kernel");
+    snprintf(buf + used, len - used, " + vs_out_power_%skernel + vs_out_noise_kernel", (ws && p->pow_lframe) ? "fill_" : "");
   }
   return VS_OK;
 }
@@ -1009,6 +1015,10 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   } else {
     /* (the launcher takes the wave-specialised kernels for the fused kind without a log only) */
     const int ws = p->wave_specialised != 0 && kind == VS_KIND_SYNTH && a.log == NULL;
+    if (ws && a.ondw && p->pow_lframe) { /* -> vs_synth_ws_pow_kernel */
+      a.odone = p->d_odone;
+      a.pow_lframe = p->pow_lframe;
+    }
     VS_HIP(ctx, vs_launch_kernel(ctx->arith, kind, a.log != NULL, ws != 0, p->pre1 != 0, &a, p->grid,
                                  ws ? p->lds_bytes : p->lds_one_wave, ctx->stream));
   }

@@ -33,6 +33,76 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
 }
 
 /*
+ * vowel -n inside the fused kernels (vowel_new.c:303-309): the filter wavefront of a wave-specialised kernel whose lanes
+ * share one position and one frame length sums (float)y*y as its results are packed -- in sample order, so the float
+ * rounding sequence is the reference's -- and at a frame's last sample (frames end on multiples of 4 samples: Lframe is
+ * a multiple of 100, a super-step starts on a multiple of 24) turns the sum into that frame's NoiseDistWidth.  Three
+ * vector instructions per sample in place of a 2 B/sample streaming pass over the finished PCM.  What it cannot vouch for
+ * it leaves to that pass (vs_out_power_kernel, fill mode): a frame during which round2int()'s quirk path rounded a
+ * super-step again gets NaN, and frames behind the last whole super-step are not counted in done[].
+ */
+#define VS_ONDW_UNKNOWN 0x7FC00000u /* NaN: "this frame's power is the streaming pass's to find" */
+struct VsFramePower {
+  float sum;   /* aux of vowel_new.c:303-306 for the frame this lane is in */
+  int tb;      /* wave-uniform: the frame ends behind sample tb - 1 of the super-step being run (4, 8, .. 24), 0: not in it */
+  int len;     /* wave-uniform: samples of the frame that ends there (ni of vw:307) */
+  int frame;   /* wave-uniform: index of the frame the super-step starts in */
+  bool bad;    /* wave-uniform: the frame the super-step starts in has seen the quirk path */
+  bool requirk; /* wave-uniform: ... and so has this super-step (the caller folds it into `bad` of the frame it ends in) */
+  bool force;  /* wave-uniform, tests (VS_FAULT_REROUND): this super-step takes the quirk path whatever its arguments */
+  /* what a lane needs at a frame's end -- its record (out_snr, row), the table -- is looked up THERE, once per 800 or 1100
+   * samples: the super-step has no register to spare for it (168 per wavefront in the three-role kernels) */
+  const VsDevLane *lanes;
+  float *ondw;
+  long ondw_pitch;
+  long first_lane; /* wave-uniform: record index of this wavefront's lane 0 */
+  int n_lanes;
+};
+/* sqrt(v) correctly rounded to double whatever the last bit of the device sqrt: s is at most
+ * one ulp off, the residual r = v - s*s is exact in one fma, and the true root lies beyond
+ * s + ulp/2 exactly when r > s*ulp (a root of a double is never a rounding midpoint). */
+__device__ __forceinline__ double vs_sqrt_rn(double v)
+{
+  double s = sqrt(v);
+  if (!(v > 0.0) || !(s > 0.0)) return s;
+  const double r = __builtin_fma(-s, s, v);
+  const double up = __longlong_as_double(__double_as_longlong(s) + 1) - s; /* ulp above s */
+  const double dn = s - __longlong_as_double(__double_as_longlong(s) - 1); /* ulp below s */
+  if (r > s * up) s = s + up;
+  else if (-r > s * dn) s = s - dn;
+  return s;
+}
+/* NoiseDistWidth = sqrt(12*sig_power/snr), sig_power = aux/(float)ni: float arithmetic, the root through double (vw:307-309) */
+__device__ __forceinline__ float vs_noise_width(float aux, int ni, float snr)
+{
+  const float sig_power = aux / (float)ni;
+  return (float)vs_sqrt_rn((double)(12.0f * sig_power / snr));
+}
+/* two results as they are packed: aux += (float)y*y, low sample first */
+__device__ __forceinline__ void vs_power_pair(uint32_t w, float &aux)
+{
+  const float lo = (float)(int)(int16_t)(w & 0xFFFFu), hi = (float)((int)w >> 16);
+  aux += lo * lo;
+  aux += hi * hi;
+}
+/* the frame's entry of the table: its width from the sum, or "unknown" */
+__device__ __forceinline__ void vs_frame_power_store(const VsFramePower &fp, bool unknown)
+{
+  const long gl = fp.first_lane + (long)(threadIdx.x & (VS_WAVE - 1));
+  if (gl < (long)fp.n_lanes) {
+    const VsDevLane *__restrict__ L = fp.lanes + gl;
+    const float snr = L->out_snr;
+    if (snr > 0.0f)
+      fp.ondw[(long)L->row * fp.ondw_pitch + fp.frame] = unknown ? __uint_as_float(VS_ONDW_UNKNOWN) : vs_noise_width(fp.sum, fp.len, snr);
+  }
+}
+__device__ __forceinline__ void vs_frame_power_flush(VsFramePower &fp)
+{
+  vs_frame_power_store(fp, fp.bad);
+  fp.sum = 0.0f;
+}
+
+/*
  * One filter super-step of one lane: 24 samples of vowel_new.c:266-289 starting at the lane's
  * own position n.  x comes from the lane's ring column (rp = &ring[rslot][lane], never wraps
  * inside a super-step because ring_slots is a multiple of VS_SS and rslot advances by VS_SS
@@ -41,14 +111,15 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
  * wave-specialised kernel and must not store).  y[] is the rotating window of the last 24 outputs
  * in double (y[t] = y at n+t-24 on entry, = y at n+t on exit).
  */
-template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1, bool LATE = false>
+template <int ARITH, int KIND, bool PRE1 = false, bool PACKED = false, int WHOLE = -1, bool LATE = false, bool POW = false>
 __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], double (&y)[VS_SS],
                                              double gain, double pre, const int16_t *rp,
                                              const int16_t *__restrict__ irow,
                                              int16_t *__restrict__ orow, int n, int N, bool vec_ok,
                                              int (&outv)[VS_SS], vs_u32x4 (&xnext)[VS_SS / 8],
-                                             bool store_ok = true)
+                                             bool store_ok = true, VsFramePower *fp = nullptr)
 {
+  static_assert(!POW || (PACKED && WHOLE == 1), "frame powers ride on the eager packing of the branch-free super-step");
   /* WHOLE: the caller has taken this decision out of its loop (1: 16-byte stores, 0: sample by sample).
    * With it -- and store_ok a constant -- nothing branches between the ring reads and their use. */
   const bool whole = (WHOLE < 0) ? (vec_ok && (n + VS_SS <= N)) : (WHOLE != 0);
@@ -210,15 +281,26 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       }
       y[t] = acc; /* replaces y[n-24]; the window rotates by renaming, vowel_new.c:287-289 */
       if (EAGER && (t & 1)) pk[(t >> 1) % PKN] = vs_clamp_pack16(outv[t - 1], outv[t]);
+      if (POW && (t & 1)) {
+        vs_power_pair(pk[(t >> 1) % PKN], fp->sum);
+        if ((t & 3) == 3 && fp->tb == t + 1) vs_frame_power_flush(*fp); /* (wave-uniform) */
+      }
       if ((t & 7) == 7) put8(t >> 3);
       /* keep each sample's products next to its chain: hoisted across samples they only park
        * in the accumulator registers and come back, two moves each way */
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu))) {
+    /* (the tolerance mode of the packed super-steps has no quirk path: it rounds to nearest-even, once) */
+    if (__any((qhi <= VS_R2I_Q1_HI) || (qlo == 0xFFFFFFFFu)) || (POW && ARITH == VS_ARITH_EXACT && fp->force)) {
       /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
        * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again,
        * literally, and store it again */
+      if (POW) {
+        /* the sums have seen the first rounding: the frame this super-step ends in, and the one that ended inside it
+         * (its width is in the table already), are left to the streaming pass */
+        if (fp->tb) vs_frame_power_store(*fp, true);
+        fp->requirk = true;
+      }
 #pragma unroll
       for (int t = 0; t < VS_SS; ++t) {
         const double y1 = (t == 0) ? ym1 : y[t - 1];

@@ -96,6 +96,9 @@ typedef struct VsKernelArgs {
   int gen_min;        /* wave-specialised kernel: generate when want lanes * 64 >= needing lanes * gen_min */
   float *ondw;        /* vowel -n: NoiseDistWidth of every frame [n_lanes][ondw_pitch] (vs_out_power_kernel -> vs_out_noise_kernel), NULL when no lane asks for it */
   long ondw_pitch;
+  int32_t *odone;     /* vowel -n behind a wave-specialised kernel that takes the frame powers along (pow_lframe > 0): frames of row r it has
+                         dealt with, [n_lanes]; the streaming pass fills in the rest.  NULL: the streaming pass does every frame */
+  int pow_lframe;     /* ... the frame length every lane of the launch shares, 0: lanes differ (or no lane asks for output noise) */
   int gen_low;        /* wave-specialised kernel: a lane with fewer buffered samples than this starts a round at once */
   int *err;           /* device word: bit 0/1 set when a bounded spin of the generator/filter wave ran out */
   int spin_limit;     /* polls before a waiting wave gives up and sets err */

@@ -88,6 +88,8 @@ struct vs_plan {
   int16_t *d_sink;            /* VsKernelArgs.sink */
   float *d_ondw;              /* vowel -n: NoiseDistWidth per frame [n_lanes][ondw_pitch], NULL if unused */
   long ondw_pitch;
+  int32_t *d_odone;           /* ... frames per row the fused kernel has dealt with itself (VsKernelArgs.odone), NULL if it never does */
+  int pow_lframe;             /* ... the frame length all lanes share when it does, else 0 */
   int wave_specialised;
   int ws_pairs;      /* groups of 64 utterances per workgroup of the wave-specialised launch */
   int ws_roles;      /* wavefronts per group: 2 or 3 (VsKernelArgs.ws_roles) */

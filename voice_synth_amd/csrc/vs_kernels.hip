@@ -459,7 +459,7 @@ __device__ __forceinline__ void vs_noise_wave(const VsKernelArgs &args, const Vs
  * PARTIAL: groups whose threshold is below 64 lanes run super-steps with the ready lanes only (the
  * two-role kernel); without it every group waits for all of its live lanes (the three-role kernel:
  * the second copy of the window that a partial super-step needs does not fit its 168 registers). */
-template <int ARITH, bool PRE1, bool PARTIAL>
+template <int ARITH, bool PRE1, bool PARTIAL, bool POW>
 __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const VsGroup &g)
 {
   const int lane = g.lane, N = g.N, C = g.C;
@@ -537,17 +537,53 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
      * around the 16-byte stores. */
     if (!valid) orow = args.sink;
     const int n_whole = (args.vec_ok != 0) ? (N / VS_SS) * VS_SS : 0;
+    /* POW: vowel -n's frame powers on the way (VsFramePower, vs_dev_filter.h) -- every lane of the launch has frames of
+     * args.pow_lframe samples, and the lanes of this wavefront share one position, so where a frame ends is a scalar */
+    VsFramePower fp;
+    int f_len = 0, f_left = 0; /* length of the frame the next super-step starts in; what is left of it */
+    if (POW) {
+      fp.sum = 0.0f;
+      fp.frame = 0;
+      fp.bad = fp.requirk = false;
+      fp.lanes = args.lanes;
+      fp.ondw = args.ondw;
+      fp.ondw_pitch = args.ondw_pitch;
+      fp.first_lane = g.group * VS_WAVE;
+      fp.n_lanes = args.n_lanes;
+      f_len = f_left = (args.pow_lframe < N) ? args.pow_lframe : N;
+    }
     int n = 0;
     for (; n < n_whole; n += VS_SS) {
       VS_DIAG_ADD(dg, 7)
       await(n);
       int outv[VS_SS];
       vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                                 N, true, outv, xpre, true);
+      if (POW) {
+        fp.tb = (f_left <= VS_SS) ? f_left : 0;
+        fp.len = f_len;
+        fp.force = (args.fault == VS_FAULT_REROUND) && ((n / VS_SS) % 7 == 3);
+      }
+      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL, POW>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                                      N, true, outv, xpre, true, &fp);
+      if (POW) {
+        if (fp.tb) { /* a frame ended behind sample tb - 1; the rest of the super-step went to the next one's sum */
+          fp.frame += 1;
+          fp.bad = fp.requirk;
+          const int rest = N - (n + fp.tb);
+          f_len = (args.pow_lframe < rest) ? args.pow_lframe : rest;
+          f_left = f_len - (VS_SS - fp.tb);
+        } else {
+          fp.bad = fp.bad || fp.requirk;
+          f_left -= VS_SS;
+        }
+        fp.requirk = false;
+      }
       release(n + VS_SS);
       VS_DIAG_ADD(dg, 0)
     }
+    /* frames [0, fp.frame) have their width (or NaN) in the table; the one in progress and whatever the sample-by-sample
+     * super-steps below complete are the streaming pass's */
+    if (POW && valid) args.odone[g.row] = fp.frame;
     for (; n < N; n += VS_SS) {
       VS_DIAG_ADD(dg, 7)
       await(n);
@@ -560,7 +596,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
     }
   } else {
     /* shallower rings: a super-step as soon as ready_min/64 of the live lanes hold 24 samples; every
-     * lane has its own position n */
+     * lane has its own position n (no frame powers on the way: all of them are the streaming pass's) */
+    if (POW && valid) args.odone[g.row] = 0;
     double y[VS_SS];
 #pragma unroll
     for (int j = 0; j < VS_SS; ++j) y[j] = 0.0; /* vowel_new.c:222-224 */
@@ -632,8 +669,8 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
  * out role-major: role = wavefront / groups.  Two roles: 0 generator, 1 filter.  Three roles: 0 open
  * phase, 1 noise, 2 filter (the hardware prefers the older of two wavefronts of equal priority:
  * open phase before noise is the better order, tools/ubench/ubench4.hip). */
-template <int ARITH, bool PRE1, int ROLES>
-__global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs args)
+template <int ARITH, bool PRE1, int ROLES, bool POW>
+__device__ __forceinline__ void vs_synth_ws_body(const VsKernelArgs &args)
 {
   extern __shared__ __attribute__((aligned(16))) int16_t lds_base[];
 
@@ -697,9 +734,20 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
 #ifdef VS_TIMING_FILTER_ONLY
   if (role != ROLES - 1) return;
 #endif
-  if (role == ROLES - 1) vs_filter_wave<ARITH, PRE1, ROLES == 2>(args, g);
+  if (role == ROLES - 1) vs_filter_wave<ARITH, PRE1, ROLES == 2, POW>(args, g);
   else if (ROLES == 3 && role == 1) vs_noise_wave(args, g);
   else vs_generator_wave<ROLES == 3>(args, g);
+}
+template <int ARITH, bool PRE1, int ROLES>
+__global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKernelArgs args)
+{
+  vs_synth_ws_body<ARITH, PRE1, ROLES, false>(args);
+}
+/* the same with vowel -n's frame powers taken along by the filter wavefronts (VsFramePower, vs_dev_filter.h) */
+template <int ARITH, bool PRE1, int ROLES>
+__global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_pow_kernel(VsKernelArgs args)
+{
+  vs_synth_ws_body<ARITH, PRE1, ROLES, true>(args);
 }
 
 /*
@@ -717,21 +765,6 @@ __global__ void __launch_bounds__(ROLES * 4 * VS_WAVE) vs_synth_ws_kernel(VsKern
  *                        to sample n -- two Philox blocks per thread, every sample independent.
  * 2 B/sample read + 4 B/sample read and written, only when asked for.
  */
-/* sqrt(v) correctly rounded to double whatever the last bit of the device sqrt: s is at most
- * one ulp off, the residual r = v - s*s is exact in one fma, and the true root lies beyond
- * s + ulp/2 exactly when r > s*ulp (a root of a double is never a rounding midpoint). */
-__device__ __forceinline__ double vs_sqrt_rn(double v)
-{
-  double s = sqrt(v);
-  if (!(v > 0.0) || !(s > 0.0)) return s;
-  const double r = __builtin_fma(-s, s, v);
-  const double up = __longlong_as_double(__double_as_longlong(s) + 1) - s; /* ulp above s */
-  const double dn = s - __longlong_as_double(__double_as_longlong(s) - 1); /* ulp below s */
-  if (r > s * up) s = s + up;
-  else if (-r > s * dn) s = s - dn;
-  return s;
-}
-
 /* aux += (float)y*y over the 8 samples of 16 bytes of a row, in sample order (vowel_new.c:304-306) */
 __device__ __forceinline__ void vs_power8(const vs_u32x4 v, float &aux)
 {
@@ -743,23 +776,16 @@ __device__ __forceinline__ void vs_power8(const vs_u32x4 v, float &aux)
   }
 }
 
+/* NoiseDistWidth of frame fr of the utterance of record L (row `row`), or of nothing (NaN is never read) behind its end */
 template <bool VEC>
-__global__ void __launch_bounds__(256) vs_out_power_kernel(VsKernelArgs args)
+__device__ __forceinline__ float vs_frame_width(const VsKernelArgs &args, const VsDevLane *__restrict__ L, long row, int fr, float snr)
 {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long l = gid / args.ondw_pitch;
-  if (l >= (long)args.n_lanes) return;
-  const int fr = (int)(gid - l * args.ondw_pitch);
-  const VsDevLane *__restrict__ L = args.lanes + l;
-  const float snr = L->out_snr;
-  if (!(snr > 0.0f)) return;
   const int N = args.n_samples;
   const int Lframe = L->Lframe;
   const long f0 = (long)fr * Lframe;
-  if (f0 >= N) return;
+  if (f0 >= N) return __uint_as_float(VS_ONDW_UNKNOWN);
   const int left = N - (int)f0;
   const int ni = (left < Lframe) ? left : Lframe;
-  const long row = (long)L->row;
   const int16_t *__restrict__ fp = args.out + row * args.out_pitch + f0;
   float aux = 0.0f;
   int i = 0;
@@ -784,8 +810,41 @@ __global__ void __launch_bounds__(256) vs_out_power_kernel(VsKernelArgs args)
     const float f = (float)fp[i];
     aux += f * f;
   }
-  const float sig_power = aux / (float)ni;
-  args.ondw[row * args.ondw_pitch + fr] = (float)vs_sqrt_rn((double)(12.0f * sig_power / snr));
+  return vs_noise_width(aux, ni, snr);
+}
+
+/* every frame: one thread per (utterance, frame) */
+template <bool VEC>
+__global__ void __launch_bounds__(256) vs_out_power_kernel(VsKernelArgs args)
+{
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long l = gid / args.ondw_pitch;
+  if (l >= (long)args.n_lanes) return;
+  const int fr = (int)(gid - l * args.ondw_pitch);
+  const VsDevLane *__restrict__ L = args.lanes + l;
+  const float snr = L->out_snr;
+  if (!(snr > 0.0f)) return;
+  const long row = (long)L->row;
+  args.ondw[row * args.ondw_pitch + fr] = vs_frame_width<VEC>(args, L, row, fr, snr);
+}
+
+/* Behind a fused kernel that took the frame powers along (vs_synth_ws_pow_kernel): one thread per utterance looks through
+ * its row of the table and does what that kernel left -- the frames behind its last whole super-step (args.odone[row] says
+ * where they start) and the ones it marked unknown because the quirk path of round2int() ran during them (VsFramePower). */
+template <bool VEC>
+__global__ void __launch_bounds__(64) vs_out_power_fill_kernel(VsKernelArgs args)
+{
+  const long l = (long)blockIdx.x * 64 + threadIdx.x;
+  if (l >= (long)args.n_lanes) return;
+  const VsDevLane *__restrict__ L = args.lanes + l;
+  const float snr = L->out_snr;
+  if (!(snr > 0.0f)) return;
+  const long row = (long)L->row;
+  float *__restrict__ wrow = args.ondw + row * args.ondw_pitch;
+  const int done = args.odone[row];
+  const int frames = (int)(((long)args.n_samples + L->Lframe - 1) / L->Lframe);
+  for (int fr = 0; fr < frames; ++fr)
+    if (fr >= done || __float_as_uint(wrow[fr]) == VS_ONDW_UNKNOWN) wrow[fr] = vs_frame_width<VEC>(args, L, row, fr, snr);
 }
 
 /* One noise sample, literally (vowel_new.c:315-317); r = the draw, what random() returns. */
@@ -843,59 +902,89 @@ __device__ __forceinline__ uint32_t vs_onoise_sub2(uint32_t ypair, int r0, int r
   return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(vs_i16x2, d), floor_));
 }
 
+/* VS_ONOISE_OCTETS octets of 8 samples per thread, 256 threads apart (measurement builds: -DVS_ONOISE_OCTETS=1 ...) */
+#ifndef VS_ONOISE_OCTETS
+#define VS_ONOISE_OCTETS 1
+#endif
+#ifndef VS_ONOISE_ROWMAJOR
+#define VS_ONOISE_ROWMAJOR 1
+#endif
 template <bool VEC>
-__global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args)
+__global__ void __launch_bounds__(256) vs_out_noise_kernel(VsKernelArgs args, unsigned segs, unsigned seg_magic, unsigned seg_shift)
 {
-  /* blockIdx.x = the utterance: its key, frame length and row are wave-uniform */
-  const VsDevLane *__restrict__ L = args.lanes + blockIdx.x;
+  constexpr int OCT = VS_ONOISE_OCTETS;
+  /* one workgroup = 256 * OCT octets of ONE utterance: its key, frame length and row are wave-uniform */
+#if VS_ONOISE_ROWMAJOR
+  /* consecutive workgroups walk along a row: utterance = block / segs by the launcher's multiplier (scalar) */
+  const unsigned lane_idx = (segs == 1u) ? blockIdx.x : ((unsigned)(((unsigned long long)blockIdx.x * seg_magic) >> 32) >> seg_shift);
+  const unsigned seg = blockIdx.x - lane_idx * segs;
+#else
+  const unsigned lane_idx = blockIdx.x, seg = blockIdx.y;
+#endif
+  const VsDevLane *__restrict__ L = args.lanes + lane_idx;
   const float snr = L->out_snr;
   if (!(snr > 0.0f)) return;
   const int N = args.n_samples;
-  const int i0 = (int)((blockIdx.y * 256u + threadIdx.x) * 8u);
-  if (i0 >= N) return;
+  const int base = (int)((seg * (256u * OCT) + threadIdx.x) * 8u);
+  if (base >= N) return;
   const long row = (long)L->row;
-  int16_t *__restrict__ op = args.out + row * args.out_pitch + i0;
-  /* the frames of the two quads (Lframe is a multiple of 4, not of 8): i / Lframe by the record's multiplier */
+  int16_t *__restrict__ orow = args.out + row * args.out_pitch;
+  const float *__restrict__ wrow = args.ondw + row * args.ondw_pitch;
   const uint32_t magic = L->lframe_magic;
   const int sh = 31 - __builtin_clz((unsigned)(L->Lframe - 1)); /* ceil(log2(Lframe)) - 1 */
-  const int fr0 = (int)(__umulhi((uint32_t)i0, magic) >> sh);
-  const int fr1 = (i0 + 4 < N) ? (int)(__umulhi((uint32_t)(i0 + 4), magic) >> sh) : fr0;
-  const float *__restrict__ wrow = args.ondw + row * args.ondw_pitch;
-  const float w0 = wrow[fr0], w1 = wrow[fr1];
-  const bool whole = VEC && (i0 + 8 <= N);
-  vs_u32x4 yp; /* the 8 samples, packed as they lie in the row */
-  if (whole) {
-    yp = *(const vs_u32x4 *)op;
-  } else {
+  const uint32_t k0 = L->okey0, k1 = L->okey1;
+  vs_u32x4 yp[OCT]; /* 8 samples each, packed as they lie in the row */
+  float w0[OCT], w1[OCT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      yp[e] = vs_pack16((i0 + 2 * e < N) ? (int)op[2 * e] : 0, (i0 + 2 * e + 1 < N) ? (int)op[2 * e + 1] : 0);
-  }
-  uint32_t o[8];
-  vs_philox((uint32_t)(i0 >> 2), L->okey0, L->okey1, o[0], o[1], o[2], o[3]);
-  vs_philox((uint32_t)(i0 >> 2) + 1u, L->okey0, L->okey1, o[4], o[5], o[6], o[7]);
-  if (vs_onoise_width_is_plain(w0) && vs_onoise_width_is_plain(w1)) {
-    const double d0 = (double)w0, d1 = (double)w1, h0 = -0.5 * d0, h1 = -0.5 * d1;
+  for (int c = 0; c < OCT; ++c) {
+    const int i0 = base + c * 2048;
+    if (i0 >= N) continue;
+    const int16_t *op = orow + i0;
+    if (VEC && (i0 + 8 <= N)) {
+      yp[c] = *(const vs_u32x4 *)op;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r0 = vs_onoise_neg_round_of_draw(o[2 * e], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
-      const int r1 = vs_onoise_neg_round_of_draw(o[2 * e + 1], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
-      yp[e] = vs_onoise_sub2(yp[e], r0, r1);
+      for (int e = 0; e < 4; ++e)
+        yp[c][e] = vs_pack16((i0 + 2 * e < N) ? (int)op[2 * e] : 0, (i0 + 2 * e + 1 < N) ? (int)op[2 * e + 1] : 0);
     }
-  } else {
-    int y[8];
-    vs_unpack8(yp, y);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      yp[e] = vs_clamp_pack16(vs_onoise_literal(y[2 * e], o[2 * e] >> 1, (e < 2) ? w0 : w1),
-                              vs_onoise_literal(y[2 * e + 1], o[2 * e + 1] >> 1, (e < 2) ? w0 : w1));
+    /* the frames of the two quads (Lframe is a multiple of 4, not of 8): i / Lframe by the record's multiplier */
+    const int fr0 = (int)(__umulhi((uint32_t)i0, magic) >> sh);
+    const int fr1 = (i0 + 4 < N) ? (int)(__umulhi((uint32_t)(i0 + 4), magic) >> sh) : fr0;
+    w0[c] = wrow[fr0];
+    w1[c] = wrow[fr1];
   }
-  if (whole) {
-    *(vs_u32x4 *)op = yp;
-  } else {
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (i0 + k < N) op[k] = (int16_t)((k & 1) ? (yp[k >> 1] >> 16) : (yp[k >> 1] & 0xFFFFu));
+  for (int c = 0; c < OCT; ++c) {
+    const int i0 = base + c * 2048;
+    if (i0 >= N) continue;
+    int16_t *op = orow + i0;
+    uint32_t o[8];
+    vs_philox((uint32_t)(i0 >> 2), k0, k1, o[0], o[1], o[2], o[3]);
+    vs_philox((uint32_t)(i0 >> 2) + 1u, k0, k1, o[4], o[5], o[6], o[7]);
+    vs_u32x4 v = yp[c];
+    if (vs_onoise_width_is_plain(w0[c]) && vs_onoise_width_is_plain(w1[c])) {
+      const double d0 = (double)w0[c], d1 = (double)w1[c], h0 = -0.5 * d0, h1 = -0.5 * d1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r0 = vs_onoise_neg_round_of_draw(o[2 * e], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
+        const int r1 = vs_onoise_neg_round_of_draw(o[2 * e + 1], (e < 2) ? d0 : d1, (e < 2) ? h0 : h1);
+        v[e] = vs_onoise_sub2(v[e], r0, r1);
+      }
+    } else {
+      int y[8];
+      vs_unpack8(v, y);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = vs_clamp_pack16(vs_onoise_literal(y[2 * e], o[2 * e] >> 1, (e < 2) ? w0[c] : w1[c]),
+                               vs_onoise_literal(y[2 * e + 1], o[2 * e + 1] >> 1, (e < 2) ? w0[c] : w1[c]));
+    }
+    if (VEC && (i0 + 8 <= N)) {
+      *(vs_u32x4 *)op = v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i0 + k < N) op[k] = (int16_t)((k & 1) ? (v[k >> 1] >> 16) : (v[k >> 1] & 0xFFFFu));
+    }
   }
 }
 
@@ -904,14 +993,33 @@ extern "C" hipError_t vs_launch_out_noise(const VsKernelArgs *args, hipStream_t 
   if (!args->ondw || args->ondw_pitch <= 0) return hipErrorInvalidValue;
   const long frames = (long)args->n_lanes * args->ondw_pitch;
   const long pblocks = (frames + 255) / 256;
-  const long segs = ((long)args->n_samples + 2047) / 2048; /* 256 threads x 8 samples */
-  if (pblocks > 0x7FFFFFFFL || segs > 65535L) return hipErrorInvalidValue;
+  const long per_block = 2048L * VS_ONOISE_OCTETS; /* 256 threads x 8 samples x octets */
+  const long segs = ((long)args->n_samples + per_block - 1) / per_block;
+  if (pblocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
+#if VS_ONOISE_ROWMAJOR
+  const long nblocks = segs * (long)args->n_lanes;
+  if (nblocks > 0x7FFFFFFFL) return hipErrorInvalidValue;
+  /* block / segs for every block < 2^31: the multiplier of vs_lframe_magic (csrc/vs_planhost.c); segs = 1: the block itself */
+  unsigned k = 0;
+  while ((1ull << k) < (unsigned long long)segs) k++;
+  const unsigned seg_magic = segs > 1 ? (unsigned)(((1ull << (31 + k)) / (unsigned long long)segs) + 1ull) : 0u;
+  const unsigned seg_shift = segs > 1 ? k - 1 : 0u;
+  const dim3 grid((unsigned)nblocks);
+#else
+  if (segs > 65535L) return hipErrorInvalidValue;
+  const unsigned seg_magic = 0, seg_shift = 0;
+  const dim3 grid((unsigned)args->n_lanes, (unsigned)segs);
+#endif
+  const bool fill = args->odone != nullptr; /* the fused kernel took the frame powers along */
+  const dim3 fgrid((unsigned)((args->n_lanes + 63) / 64));
   if (args->vec_ok) {
-    hipLaunchKernelGGL(vs_out_power_kernel<true>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
-    hipLaunchKernelGGL(vs_out_noise_kernel<true>, dim3((unsigned)args->n_lanes, (unsigned)segs), dim3(256), 0, stream, *args);
+    if (fill) hipLaunchKernelGGL(vs_out_power_fill_kernel<true>, fgrid, dim3(64), 0, stream, *args);
+    else hipLaunchKernelGGL(vs_out_power_kernel<true>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(vs_out_noise_kernel<true>, grid, dim3(256), 0, stream, *args, (unsigned)segs, seg_magic, seg_shift);
   } else {
-    hipLaunchKernelGGL(vs_out_power_kernel<false>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
-    hipLaunchKernelGGL(vs_out_noise_kernel<false>, dim3((unsigned)args->n_lanes, (unsigned)segs), dim3(256), 0, stream, *args);
+    if (fill) hipLaunchKernelGGL(vs_out_power_fill_kernel<false>, fgrid, dim3(64), 0, stream, *args);
+    else hipLaunchKernelGGL(vs_out_power_kernel<false>, dim3((unsigned)pblocks), dim3(256), 0, stream, *args);
+    hipLaunchKernelGGL(vs_out_noise_kernel<false>, grid, dim3(256), 0, stream, *args, (unsigned)segs, seg_magic, seg_shift);
   }
   return hipGetLastError();
 }
@@ -1255,6 +1363,17 @@ static vs_kernel_fn vs_pick_log(bool log)
 }
 
 #if VS_GROUP_LANES == VS_WAVE
+template <int ARITH, bool PRE1>
+static vs_kernel_fn vs_pick_ws2(bool three, bool pow)
+{
+  if (three) return pow ? (vs_kernel_fn)vs_synth_ws_pow_kernel<ARITH, PRE1, 3> : (vs_kernel_fn)vs_synth_ws_kernel<ARITH, PRE1, 3>;
+  return pow ? (vs_kernel_fn)vs_synth_ws_pow_kernel<ARITH, PRE1, 2> : (vs_kernel_fn)vs_synth_ws_kernel<ARITH, PRE1, 2>;
+}
+static vs_kernel_fn vs_pick_ws(int arith, bool pre1, bool three, bool pow)
+{
+  if (arith == VS_ARITH_EXACT) return pre1 ? vs_pick_ws2<VS_ARITH_EXACT, true>(three, pow) : vs_pick_ws2<VS_ARITH_EXACT, false>(three, pow);
+  return pre1 ? vs_pick_ws2<VS_ARITH_FMA, true>(three, pow) : vs_pick_ws2<VS_ARITH_FMA, false>(three, pow);
+}
 extern "C" hipError_t vs_launch_kernel_narrow(int arith, int kind, bool log, bool pre1, const VsKernelArgs *args,
                                               unsigned grid, size_t lds_bytes, hipStream_t stream);
 #define VS_LAUNCH_NAME vs_launch_kernel
@@ -1277,13 +1396,9 @@ extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_sp
   }
   if (wave_specialised && kind == VS_KIND_SYNTH && !log) {
     const bool three = args->ws_roles == 3;
-    if (arith == VS_ARITH_EXACT) {
-      if (three) fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 3>;
-      else fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, true, 2> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_EXACT, false, 2>;
-    } else {
-      if (three) fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, true, 3> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 3>;
-      else fn = pre1 ? (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, true, 2> : (vs_kernel_fn)vs_synth_ws_kernel<VS_ARITH_FMA, false, 2>;
-    }
+    /* vowel -n with one frame length for the whole launch: the filter wavefronts take the frame powers along */
+    const bool pow = args->ondw && args->odone && args->pow_lframe > 0;
+    fn = vs_pick_ws(arith, pre1, three, pow);
     /* lds_bytes arrives as the bytes of ONE group (ring + cos rows + progress words); args->ws_pairs
      * groups share a workgroup, args->ws_roles wavefronts serve each */
     block = (unsigned)args->ws_roles * VS_WAVE * (unsigned)args->ws_pairs;

@@ -234,6 +234,8 @@ static void stats_lane(VsBatchStats *st, const vs_lane *lane, const VsDevLane *d
   if (d->T2 > st->max_T2) st->max_T2 = d->T2;
   if (d->tbound > st->tmax) st->tmax = d->tbound;
   if (d->Lframe > 0 && (st->min_lframe == 0 || d->Lframe < st->min_lframe)) st->min_lframe = d->Lframe;
+  if (d->Lframe > st->max_lframe) st->max_lframe = d->Lframe;
+  if (d->Lframe <= 0) st->no_lframe = 1;
   if (d->out_snr > 0) st->any_onoise = 1;
   if (d->pre != 1.0) st->pre1 = 0;
   if (vs_lane_is_wide(lane)) st->wide = 1;
@@ -245,6 +247,8 @@ static void stats_merge(VsBatchStats *a, const VsBatchStats *b)
   if (b->max_T2 > a->max_T2) a->max_T2 = b->max_T2;
   if (b->tmax > a->tmax) a->tmax = b->tmax;
   if (b->min_lframe > 0 && (a->min_lframe == 0 || b->min_lframe < a->min_lframe)) a->min_lframe = b->min_lframe;
+  if (b->max_lframe > a->max_lframe) a->max_lframe = b->max_lframe;
+  a->no_lframe |= b->no_lframe;
   a->any_onoise |= b->any_onoise;
   a->pre1 &= b->pre1;
   a->wide |= b->wide;

@@ -35,6 +35,8 @@ typedef struct VsBatchStats {
   int max_T2;       /* longest cos row */
   int tmax;         /* longest period any lane's rejection test admits (VsDevLane.tbound) */
   int min_lframe;   /* shortest frame (> 0) of the batch, 0: none */
+  int max_lframe;   /* longest frame; == min_lframe (and no_lframe 0): every lane has the same */
+  int no_lframe;    /* some lane has no frame at all (fs < 2000) */
   int any_onoise;   /* some lane asks for vowel -n */
   int pre1;         /* every lane has pre_emphasis == 1.0 */
   int wide;         /* some lane carries a coefficient set of 23..40 taps */
