@@ -50,10 +50,13 @@ $(CSRC)/vs_planhost.o: $(CSRC)/vs_planhost.c $(CSRC)/vs_planhost.h $(CSRC)/vs_de
 $(CSRC)/vs_delivery.o: $(CSRC)/vs_delivery.c $(HOST_HDRS)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(CSRC)/vs_node.o: $(CSRC)/vs_node.c $(HOST_HDRS)
+$(CSRC)/vs_node.o: $(CSRC)/vs_node.c $(CSRC)/vs_commguard.h $(HOST_HDRS)
 	$(CC) $(HOSTFLAGS) -c -o $@ $<
 
-$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o | $(LIBDIR)
+$(CSRC)/vs_commguard.o: $(CSRC)/vs_commguard.c $(CSRC)/vs_commguard.h
+	$(CC) -std=gnu11 $(CFLAGS) -c -o $@ $<
+
+$(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o $(CSRC)/vs_kernels.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_commguard.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
@@ -78,14 +81,14 @@ clean:
 diag: $(LIBDIR)/libvoicesynth_diag.so
 $(CSRC)/vs_kernels_diag.o: $(CSRC)/vs_kernels.hip $(KERNEL_HDRS)
 	$(HIPCC) $(HIPFLAGS) -DVS_DIAG -c -o $@ $<
-$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
+$(LIBDIR)/libvoicesynth_diag.so: $(CSRC)/vs_kernels_diag.o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_commguard.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -lm -lpthread -ldl
 
 # A/B variants of the library for same-box comparisons (tools/gpu_ab.sh):
 #   make variant NAME=sleep2 DEFS="-DVS_POLL_SLEEP=2"   ->  lib/libvoicesynth_sleep2.so   (select with VS_LIB)
-variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
+variant: $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_commguard.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels.hip
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o -lm -lpthread -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libvoicesynth_$(NAME).so $(CSRC)/vs_kernels_$(NAME).o $(CSRC)/vs_kernels_narrow.o $(CSRC)/vs_api.o $(CSRC)/vs_delivery.o $(CSRC)/vs_node.o $(CSRC)/vs_commguard.o $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o -lm -lpthread -ldl
 
 # device listing of the shipped kernels (same flags) for tools/isa_loops.py
 isa:

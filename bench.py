@@ -185,7 +185,7 @@ def reference_as_shipped(specs_fn, n_samples, max_workers, target_s=6.0):
     return out
 
 
-def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
+def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None, tolerance_rows=None):
     """The CPU oracle on a bounded sample of the same workload, all host cores.  The sample
     starts at lane 0, so its first rows double as a parity spot check of what the GPU just
     produced (the only place bench.py touches oracle/)."""
@@ -259,6 +259,15 @@ def cpu_baseline(specs_fn, n_samples, target_s, gpu_first_lanes=None):
         rms = (sq / (float(k) * n_samples)) ** 0.5 if k else 0.0
         out["gpu_rms_error_lsb"] = rms
         out["gpu_rms_error_normalised"] = rms / 32768.0
+    if tolerance_rows:
+        # the opt-in arithmetics (fma, f32): first rows of their launches against the same CPU rows
+        out["tolerance_modes"] = {}
+        for name, rows in tolerance_rows.items():
+            k = min(len(rows), n_lanes)
+            d = rows[:k].astype(np.int32) - pcm[:k].astype(np.int32)
+            r = float(np.sqrt(np.mean(d.astype(np.float64) ** 2))) if k else 0.0
+            out["tolerance_modes"][name] = {"rows_checked": k, "differing_samples": int(np.count_nonzero(d)),
+                                            "max_abs_lsb": int(np.abs(d).max()) if k else 0, "lsb": r, "normalised": r / 32768.0}
     return out
 
 
@@ -602,6 +611,25 @@ def main():
     plan.status()
     other_kern = sorted(a.elapsed_time(b) for a, b in oev)
     other_ms = sum(other_kern) / len(other_kern)
+    n_tol_rows = min(4096, per_gpu)   # rows of the tolerance modes kept for their RMS against the CPU sample
+    other_rows = out[:n_tol_rows, :n_samples].cpu().numpy() if (rank == 0 and other != vs.VS_ARITH_EXACT) else None
+
+    # ---- the third arithmetic, VS_ARITH_F32 (packed single precision, opt-in: include/voice_synth.h), same treatment ----
+    eng.set_arith(vs.VS_ARITH_F32)
+    f32_kernel = plan.kernel_name(vs.VS_KIND_SYNTH)
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize(dev)
+    fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+    for a, b in fev:
+        a.record(stream)
+        launch()
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    plan.status()
+    f32_kern = sorted(a.elapsed_time(b) for a, b in fev)
+    f32_ms = sum(f32_kern) / len(f32_kern)
+    f32_rows = out[:n_tol_rows, :n_samples].cpu().numpy() if rank == 0 else None
 
     # ---- what the row pitch is worth, outside the timed region: the same plan into the same allocation with rows at the
     # pitch vs_row_pitch() names and with dense rows (16-byte multiples), launches of the two INTERLEAVED (the chip's clock
@@ -744,6 +772,13 @@ def main():
                             "kernel_ms_median": round(other_kern[len(other_kern) // 2], 4),
                             "kernel_ms_min": round(other_kern[0], 4),
                             "Msamples/s_per_gpu": round(per_gpu * n_samples / (other_ms * 1e-3) / 1e6, 1)},
+            "f32_arith": {"arith": "f32", "kernel": f32_kernel, "launches": len(f32_kern),
+                          "kernel_ms_avg": round(f32_ms, 4), "kernel_ms_median": round(f32_kern[len(f32_kern) // 2], 4),
+                          "kernel_ms_min": round(f32_kern[0], 4),
+                          "Msamples/s_per_gpu": round(per_gpu * n_samples / (f32_ms * 1e-3) / 1e6, 1),
+                          "roofline_frac": round(ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (f32_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                          "contract": "opt-in; measured distance from the reference per vowel table in tests/golden/f32_bounds.json "
+                                      "(RMS 4.6e-6 .. 1.9e-5 of full scale at the default gain); rms_vs_c_ref below is this workload's"},
             "row_pitch_ab": pitch_ab,
             "other_configs": other_configs,
             "fresh_batches": fresh,
@@ -759,9 +794,15 @@ def main():
         if rehearsal:
             result["rehearsal"] = "VS_BENCH_REHEARSAL: every rank shares device 0 over gloo (tests only; the numbers mean nothing)"
         if world == 1 and not args.no_cpu_baseline:
+            tol_rows = {"f32": f32_rows}
+            if other_rows is not None:
+                tol_rows["fma"] = other_rows
             cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples,
-                              args.cpu_seconds, first_rows)
+                              args.cpu_seconds, first_rows, tol_rows)
             result["cpu_baseline"] = cb
+            # the tolerance modes against the same CPU sample (first rows of their last launch)
+            for name, rec in (cb.pop("tolerance_modes", None) or {}).items():
+                result["f32_arith" if name == "f32" else "other_arith"]["rms_vs_c_ref"] = rec
             # the metric's second figure, next to the throughput
             result["rms_vs_c_ref"] = {"lsb": cb.get("gpu_rms_error_lsb"),
                                       "normalised": cb.get("gpu_rms_error_normalised"),

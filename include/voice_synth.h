@@ -115,8 +115,16 @@ typedef struct vs_cycle_rec {
  *                 of the option fuzz, bound +-1 LSB.  For explicit sets the distance follows the
  *                 set's conditioning (+-1 LSB measured for max |A| <= 500; a direct form of order
  *                 40 with coefficients of 1e4 moves a few samples by more). */
+/* VS_ARITH_F32:   the recurrence in single precision, two taps per packed multiply-add -- 1.25 x the speed of VS_ARITH_FMA
+ *                 for a MEASURED distance from the reference (single precision is marginal against 1e-5):
+ *                 per table at gain 10 / pre-emphasis 1, RMS of full scale 4.6e-6 (table 7) .. 1.9e-5 (/i/), above 1e-5
+ *                 for /i/, /u/ and table 1; at most 7 LSB there, 28 LSB for table 5 without pre-emphasis.  The whole table
+ *                 is tests/golden/f32_bounds.json (made by tools/f32_survey.py on the device); tests/test_gpu_f32.py holds
+ *                 the kernels to it.  Only the fused wave-specialised kernels have this arithmetic: source-only and
+ *                 filter-only launches, the one-wave kernel and coefficient sets of 23..40 taps run VS_ARITH_FMA. */
 #define VS_ARITH_EXACT 0
 #define VS_ARITH_FMA 1
+#define VS_ARITH_F32 2
 
 /* What a plan launch computes. */
 #define VS_KIND_SYNTH 0   /* source -> filter, flow never leaves the chip      (fg:246-423 + vw:237-331) */

@@ -34,6 +34,28 @@ static unsigned rnd(void)
   return rng_state >> 8;
 }
 
+/* a stand-in for the context's page-locked allocator: counts, and refuses the calls whose bit is set in big_refuse_mask */
+static int big_calls = 0, big_live = 0;
+static unsigned big_refuse_mask = 0;
+static void *big_alloc_stub(void *user, size_t bytes)
+{
+  const int k = big_calls++;
+  if (k < 32 && (big_refuse_mask >> k) & 1u) return NULL;
+  if (k >= 32 && big_refuse_mask == ~0u) return NULL;
+  char *p = (char *)malloc(bytes + 16);
+  if (!p) return NULL;
+  memcpy(p, "BIGALLOC", 8); /* a block of ours: free() of p + 16 would be caught by the sanitizer */
+  (*(int *)user)++;
+  return p + 16;
+}
+static void big_free_stub(void *user, void *ptr)
+{
+  char *p = (char *)ptr - 16;
+  if (memcmp(p, "BIGALLOC", 8) != 0) abort();
+  (*(int *)user)--;
+  free(p);
+}
+
 int main(void)
 {
   const size_t n = 20000;
@@ -208,6 +230,33 @@ int main(void)
     free(want);
     vs_planws_destroy(ws);
     vs_planws_destroy(NULL);
+  }
+
+  /* the workspace under page-locked-memory pressure: the context's allocator for big record buffers (hipHostMalloc there,
+   * a counting stand-in here) refuses its first, its second, or every request -- a batch whose lanes must be put in
+   * kernel order needs TWO buffers, and either may end up in ordinary memory; the answer is the same and every block goes
+   * back to where it came from */
+  {
+    for (int refuse = 0; refuse < 4; refuse++) {
+      big_calls = big_live = 0;
+      big_refuse_mask = (refuse == 3) ? ~0u : (1u << refuse);
+      VsPlanWs *ws = vs_planws_create();
+      CHECK(ws != NULL);
+      vs_planws_set_big_allocator(ws, big_alloc_stub, big_free_stub, &big_live);
+      VsDevLane *want = (VsDevLane *)malloc(n * sizeof(VsDevLane));
+      CHECK(want != NULL);
+      for (int round = 0; round < 2; round++) {
+        VsDevLane *got = NULL;
+        int ra = -1, rb = -1;
+        CHECK(vs_expand_all_ordered_ws(ws, lanes, n, 0, &got, &ra, NULL) == VS_OK && got != NULL && ra == 1);
+        CHECK(vs_expand_all_ordered(lanes, want, n, &rb, NULL) == VS_OK && rb == 1);
+        if (got) CHECK(memcmp(got, want, n * sizeof(VsDevLane)) == 0);
+      }
+      CHECK(big_calls >= 2);             /* both buffers were asked of the big allocator ... */
+      free(want);
+      vs_planws_destroy(ws);
+      CHECK(big_live == 0);              /* ... and what it gave has been given back to it, nothing of it to free() */
+    }
   }
 
   /* two bad lanes met by different threads: the lowest one's error is the answer */

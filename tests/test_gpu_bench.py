@@ -53,6 +53,11 @@ def test_bench_single_process_small():
     assert d["cpu_baseline"]["gpu_rows_checked"] >= 1 and d["cpu_baseline"]["gpu_mismatched_samples"] == 0
     _check_row_pitch(d, 16064)                               # rows at the pitch vs_row_pitch() names, compared with the oracle
     assert d["other_arith"]["launches"] >= 10 and d["other_arith"]["kernel_ms_min"] <= d["other_arith"]["kernel_ms_median"]
+    # the tolerance modes carry their distance from the CPU sample: fma within one LSB, f32 within its measured bounds
+    assert d["other_arith"]["rms_vs_c_ref"]["max_abs_lsb"] <= 1 and d["other_arith"]["rms_vs_c_ref"]["normalised"] <= 1e-5
+    f32 = d["f32_arith"]
+    assert f32["kernel"].startswith("vs_synth_ws_kernel<2,") and f32["launches"] >= 10 and f32["kernel_ms_min"] > 0
+    assert f32["rms_vs_c_ref"]["rows_checked"] >= 1024 and 0 < f32["rms_vs_c_ref"]["normalised"] < 4e-5 and f32["rms_vs_c_ref"]["max_abs_lsb"] <= 32
     ref = d["cpu_baseline"].get("reference_as_shipped")
     if ref:                                                  # oracle/_ref travels to the GPU box
         assert ref["matches_port"] is True

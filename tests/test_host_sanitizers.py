@@ -31,6 +31,22 @@ def test_plan_host_c_under_asan_ubsan(tmp_path):
     assert r.stdout.strip() == b"ok"
 
 
+def test_communicator_guard_ends_a_blocked_exchange(tmp_path):
+    """csrc/vs_commguard.c, the guard around the node's RCCL communicators, against a mock communicator whose calls block
+    until their peer answers (tests/c/test_commguard.c): a shard that fails before it posts its side must be able to
+    abort the exchange while its peers -- and the root -- are blocked inside their calls.  Under ASan/UBSan, and under
+    ThreadSanitizer where the toolchain has it."""
+    src = [os.path.join(ROOT, "tests", "c", "test_commguard.c"), os.path.join(ROOT, "voice_synth_amd", "csrc", "vs_commguard.c")]
+    for name, flags in (("asan", SAN), ("tsan", ["-g", "-O1", "-fsanitize=thread"])):
+        exe = str(tmp_path / ("test_commguard_" + name))
+        built = subprocess.run(["gcc", "-std=gnu11"] + flags + src + ["-o", exe, "-lpthread"], capture_output=True)
+        if built.returncode != 0 and name == "tsan":
+            continue                                  # no libtsan here: the ASan run stands
+        assert built.returncode == 0, built.stderr
+        r = subprocess.run([exe], capture_output=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == b"ok", (name, r.stdout, r.stderr)
+
+
 ORACLE_DRIVER = r"""
 #include <stdio.h>
 #include <stdlib.h>

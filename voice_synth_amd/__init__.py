@@ -19,6 +19,7 @@ from ._ffi import (  # noqa: F401
     VsError,
     VS_ARITH_EXACT,
     VS_ARITH_FMA,
+    VS_ARITH_F32,
     VS_FLAG_JITTER,
     VS_FLAG_NOISE,
     VS_FLAG_SHIMMER,

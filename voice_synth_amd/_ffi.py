@@ -33,6 +33,7 @@ VS_FLAG_NOISE = 0x4
 
 VS_ARITH_EXACT = 0
 VS_ARITH_FMA = 1
+VS_ARITH_F32 = 2
 
 VS_KIND_SYNTH = 0
 VS_KIND_SOURCE = 1

@@ -87,23 +87,22 @@ int vs_copy_path_warm(vs_ctx *ctx)
   const size_t warm_bytes = 1u << 20;
   void *host = malloc(warm_bytes);
   hipError_t e = host ? hipSetDevice(ctx->device) : hipErrorOutOfMemory;
+  /* on the stream the records of later plans go up on (creating a stream costs milliseconds the first time) -- a
+   * NON-BLOCKING stream of the context's own, never the legacy stream: that one waits for every blocking stream of the
+   * process, the caller's running kernel included, and vs_plan_create promises to run next to a launch */
+  if (e == hipSuccess && !ctx->own_upload) e = hipStreamCreateWithFlags(&ctx->own_upload, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&scratch, warm_bytes);
   if (e == hipSuccess) {
     memset(host, 0, warm_bytes);
-    e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, NULL);
-    if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, NULL);
-    if (e == hipSuccess) e = hipStreamSynchronize(NULL);
+    e = hipMemcpyAsync(scratch, host, warm_bytes, hipMemcpyHostToDevice, ctx->own_upload);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, scratch, sizeof(int), hipMemcpyDeviceToHost, ctx->own_upload);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->own_upload);
     (void)hipFree(scratch);
   }
   free(host);
   if (e != hipSuccess) {
     ctx->last_hip_error = (int)e;
     return (e == hipErrorOutOfMemory) ? VS_ERR_NOMEM : VS_ERR_HIP;
-  }
-  /* ... and the stream the records of later plans go up on (creating a stream costs milliseconds the first time) */
-  if (!ctx->own_upload && hipStreamCreateWithFlags(&ctx->own_upload, hipStreamNonBlocking) != hipSuccess) {
-    ctx->own_upload = NULL;
-    (void)hipGetLastError(); /* the plan tries again and reports it */
   }
   ctx->copy_warm = 1;
   ctx->copy_warm_ms = vs_now_ms() - t0;
@@ -156,7 +155,7 @@ int vs_ctx_set_stream(vs_ctx *ctx, void *hip_stream)
 
 int vs_ctx_set_arith(vs_ctx *ctx, int arith)
 {
-  if (!ctx || (arith != VS_ARITH_EXACT && arith != VS_ARITH_FMA)) return VS_ERR_ARG;
+  if (!ctx || (arith != VS_ARITH_EXACT && arith != VS_ARITH_FMA && arith != VS_ARITH_F32)) return VS_ERR_ARG;
   ctx->arith = arith;
   return VS_OK;
 }
@@ -201,16 +200,21 @@ static int simd_probe(vs_ctx *ctx)
   ctx->simd_odd_wgs = 0;
   if (!h) return VS_ERR_NOMEM;
   hipError_t e = hipSetDevice(ctx->device);
+  /* on the context's own non-blocking stream, not the caller's launch stream: the first plan that wants a three-role
+   * layout may be made while a kernel of the caller's runs there (the probe still needs the CUs: it starts when they are
+   * free, but it does not make vs_plan_create wait for work that was queued behind that kernel) */
+  if (e == hipSuccess && !ctx->own_upload) e = hipStreamCreateWithFlags(&ctx->own_upload, hipStreamNonBlocking);
+  hipStream_t ps = ctx->own_upload;
   if (e == hipSuccess) e = hipMalloc((void **)&d, (size_t)grid * 16 * sizeof(unsigned));
   int ok[2] = {1, 1};
   unsigned odd = 0;
   for (int pass = 0; pass < 2 && e == hipSuccess; pass++) {
     const int waves = pass == 0 ? 12 : 8;
     memset(h, 0, (size_t)grid * 16 * sizeof(unsigned));
-    e = hipMemcpyAsync(d, h, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = vs_launch_simd_probe(waves, grid, (size_t)VS_LDS_LIMIT - 8192, d, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h, d, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    e = hipMemcpyAsync(d, h, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyHostToDevice, ps);
+    if (e == hipSuccess) e = vs_launch_simd_probe(waves, grid, (size_t)VS_LDS_LIMIT - 8192, d, ps);
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, (size_t)grid * 16 * sizeof(unsigned), hipMemcpyDeviceToHost, ps);
+    if (e == hipSuccess) e = hipStreamSynchronize(ps);
     if (e != hipSuccess) break;
     for (unsigned g = 0; g < grid; g++) {
       /* "dealt four at a time": the first four wavefronts land on four DIFFERENT SIMDs (in whatever order -- MI355X
@@ -847,10 +851,22 @@ int vs_plan_reseed(vs_plan *p, const uint64_t *seeds, const uint64_t *out_seeds)
   VS_HIP(ctx, hipSetDevice(ctx->device));
   const size_t n = p->n_lanes;
   if (p->zc_host) return VS_ERR_INTERNAL; /* (the small calls' zero-copy plans live for one call inside vs_source / vs_filter) */
-  if (!p->d_seeds) {
-    VS_HIP(ctx, hipMalloc((void **)&p->d_seeds, 2 * n * sizeof(uint64_t)));
-    VS_HIP(ctx, hipHostMalloc((void **)&p->h_seeds, 2 * n * sizeof(uint64_t), hipHostMallocDefault));
-    VS_HIP(ctx, hipEventCreateWithFlags(&p->seeds_copied, hipEventDisableTiming));
+  if (!p->seeds_copied) {
+    /* all three or none: a first call that fails half-way leaves the plan as it was, and the next one starts over */
+    unsigned long long *d = NULL, *h = NULL;
+    hipEvent_t ev = NULL;
+    hipError_t e = hipMalloc((void **)&d, 2 * n * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h, 2 * n * sizeof(uint64_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      if (d) (void)hipFree(d);
+      if (h) (void)hipHostFree(h);
+      ctx->last_hip_error = (int)e;
+      return e == hipErrorOutOfMemory ? VS_ERR_NOMEM : VS_ERR_HIP;
+    }
+    p->d_seeds = d;
+    p->h_seeds = h;
+    p->seeds_copied = ev;
   } else {
     VS_HIP(ctx, hipEventSynchronize(p->seeds_copied)); /* the previous reseed's upload has left the pinned buffer */
   }
@@ -883,9 +899,11 @@ int vs_plan_timing(const vs_plan *p, double *host_ms, double *upload_ms)
 int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
 {
   if (!p || !buf || len == 0) return VS_ERR_ARG;
+  /* VS_ARITH_F32 is the wave-specialised kernels' alone: everything else runs VS_ARITH_FMA for it */
+  const int one_wave_arith = p->ctx->arith == VS_ARITH_F32 ? VS_ARITH_FMA : p->ctx->arith;
   if (p->wide && kind != VS_KIND_SOURCE) {
     snprintf(buf, len, "%svs_filter_wide_kernel<%d>", kind == VS_KIND_SYNTH ? "vs_synth_kernel<0, 1, false, false> + " : "",
-             p->ctx->arith);
+             one_wave_arith);
     return VS_OK;
   }
   const int ws = p->wave_specialised && kind == VS_KIND_SYNTH;
@@ -894,7 +912,7 @@ int vs_plan_kernel_name(const vs_plan *p, int kind, char *buf, size_t len)
     snprintf(buf, len, "vs_synth_ws_%skernel<%d, %s, %d>", (p->d_ondw && p->pow_lframe) ? "pow_" : "", p->ctx->arith,
              p->pre1 ? "true" : "false", p->ws_roles);
   else
-    snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : p->ctx->arith, kind,
+    snprintf(buf, len, "vs_synth_kernel<%d, %d, false, %s>%s", kind == VS_KIND_SOURCE ? 0 : one_wave_arith, kind,
              pre1 ? "true" : "false", p->group_lanes != VS_WAVE ? " (narrow build: 16 utterances per wavefront)" : "");
   if (p->d_ondw && kind != VS_KIND_SOURCE) { /* vowel -n: the two passes behind it */
     const size_t used = strlen(buf);
@@ -952,7 +970,7 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   a.ready_min = p->ready_min;
   /* a SIMD per wavefront and fused multiply-adds: the filter is as quick as the generator and does
    * better not to wait for the last lane (see the thresholds in vs_plan_create_impl) */
-  if (p->wave_specialised && !p->ws_shared_simd && p->ctx->arith == VS_ARITH_FMA && a.ready_min == 0) a.ready_min = 40;
+  if (p->wave_specialised && !p->ws_shared_simd && p->ctx->arith != VS_ARITH_EXACT && a.ready_min == 0) a.ready_min = 40;
   a.diag = p->d_diag;
   a.err = p->d_err;
   a.sink = p->d_sink;

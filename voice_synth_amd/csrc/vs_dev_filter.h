@@ -320,4 +320,109 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
   }
 }
 
+/*
+ * VS_ARITH_F32 (opt-in): the recurrence of vowel_new.c:279-281 in SINGLE precision with PACKED fused
+ * multiply-adds -- two taps per V_PK_FMA_F32 -- for callers who accept a measured distance from the reference instead of
+ * its rounding sequence (include/voice_synth.h has the table: RMS up to 1.9e-5 of full scale, 28 LSB at most, worst for
+ * /i/ at the default gain; tests/test_gpu_f32.py holds the kernels to it).  The window is 12 register pairs
+ * {y[2q], y[2q+1]} (24 registers where the double window takes 48); for an even sample index the 22 taps are 11 aligned
+ * pairs, for an odd one 10 pairs plus the newest and the oldest tap on their own: nce[k] = -{A[2k+2], A[2k+1]},
+ * nco[k] = -{A[2k+3], A[2k+2]}.  17.5 vector instructions per sample where VS_ARITH_FMA takes 29 and VS_ARITH_EXACT 52.
+ * Only the fused wave-specialised kernels have it; every other kernel (source-only and filter-only kinds, the one-wave
+ * and the wide kernel) runs VS_ARITH_FMA when the context asks for VS_ARITH_F32.
+ */
+typedef float vs_f32x2 __attribute__((ext_vector_type(2)));
+struct VsF32Filter {
+  vs_f32x2 nce[11], nco[10], yp[12];
+  float na1, na22, gain, pre;
+};
+__device__ __forceinline__ void vs_f32_load(const double *__restrict__ taps, const VsDevLane *__restrict__ L, VsF32Filter &f)
+{
+  const double *__restrict__ row = taps + (size_t)L->tap_row * VS_ORDER; /* row[j - 1] = A[j] */
+#pragma unroll
+  for (int k = 0; k < 11; ++k) f.nce[k] = (vs_f32x2){-(float)row[2 * k + 1], -(float)row[2 * k]};
+#pragma unroll
+  for (int k = 0; k < 10; ++k) f.nco[k] = (vs_f32x2){-(float)row[2 * k + 2], -(float)row[2 * k + 1]};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) f.yp[k] = (vs_f32x2){0.0f, 0.0f}; /* vowel_new.c:222-224 */
+  f.na1 = -(float)row[0];
+  f.na22 = -(float)row[21];
+  f.gain = (float)L->gain;
+  f.pre = (float)L->pre;
+}
+/* round to nearest, ties upwards, saturating: V_CVT_RPI_I32_F32 = floor(x + 0.5) in one instruction (the tolerance modes owe
+ * the reference a distance, not its half-down ties) */
+__device__ __forceinline__ int vs_round_f32(float x)
+{
+  int r;
+  asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+/* one super-step of 24 samples; WHOLE: 1 = inside the row, 16-byte stores (the branch-free loops), 0 = sample by sample
+ * against N (a row's last super-step, unaligned rows) */
+template <bool PRE1, int WHOLE, bool POW>
+__device__ __forceinline__ void vs_superstep_f32(VsF32Filter &f, const int16_t *rp, int16_t *__restrict__ orow, int n, int N,
+                                                 bool store_ok, VsFramePower *fp = nullptr)
+{
+  static_assert(!POW || WHOLE == 1, "frame powers ride on the packed stores of the branch-free super-step");
+  int xin[VS_SS];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xin[t] = (int)rp[t * VS_GROUP_LANES];
+  uint32_t pk[4];
+#pragma unroll
+  for (int m = 0; m < VS_SS / 2; ++m) {
+    if ((m & 3) == 0) {
+      if (2 * m + 8 < VS_SS) { /* the next chunk's ring samples, a chunk ahead of their use */
+#pragma unroll
+        for (int u = 2 * m + 8; u < 2 * m + 16; ++u) xin[u] = (int)rp[u * VS_GROUP_LANES];
+      }
+      /* this chunk's eight samples are all "used" here: ONE s_waitcnt for the batch instead of one per sample (vs_superstep) */
+      asm volatile("" ::"v"(xin[2 * m]), "v"(xin[2 * m + 1]), "v"(xin[2 * m + 2]), "v"(xin[2 * m + 3]), "v"(xin[2 * m + 4]),
+                   "v"(xin[2 * m + 5]), "v"(xin[2 * m + 6]), "v"(xin[2 * m + 7]));
+    }
+    int o0, o1;
+    {
+      /* even sample t = 2m: taps 1..22 are the pairs yp[m-1], yp[m-2], .. yp[m-11];
+       * odd sample t = 2m + 1: tap 1 is the sample just made, taps 2..21 the pairs yp[m-1] .. yp[m-10], tap 22 the high
+       * half of yp[m+1].  The two chains are written side by side: a packed multiply-add that reads the result of the one
+       * in front of it costs a wait state (an s_nop: an issue slot), and all of the odd sample but its newest tap is
+       * independent of the even one */
+      vs_f32x2 pe = {(float)xin[2 * m] * f.gain, 0.0f};
+      vs_f32x2 po = {(float)xin[2 * m + 1] * f.gain, 0.0f};
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        pe = __builtin_elementwise_fma(f.nce[k], f.yp[(m + 11 - k) % 12], pe);
+        po = __builtin_elementwise_fma(f.nco[k], f.yp[(m + 11 - k) % 12], po);
+      }
+      pe = __builtin_elementwise_fma(f.nce[10], f.yp[(m + 1) % 12], pe);
+      float sc = __builtin_fmaf(f.na22, f.yp[(m + 1) % 12].y, po.y);
+      const float acc0 = pe.x + pe.y;
+      sc = sc + po.x;
+      const float y1 = f.yp[(m + 11) % 12].y;
+      o0 = vs_round_f32(PRE1 ? (acc0 - y1) : __builtin_fmaf(-f.pre, y1, acc0)); /* vowel_new.c:284 */
+      const float acc1 = __builtin_fmaf(f.na1, acc0, sc);
+      o1 = vs_round_f32(PRE1 ? (acc1 - acc0) : __builtin_fmaf(-f.pre, acc0, acc1));
+      f.yp[m] = (vs_f32x2){acc0, acc1}; /* replaces y[n-24], y[n-23]: the window rotates by renaming, vowel_new.c:287-289 */
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (WHOLE == 1) {
+      pk[m & 3] = vs_clamp_pack16(o0, o1);
+      if (POW) {
+        vs_power_pair(pk[m & 3], fp->sum);
+        if ((m & 1) && fp->tb == 2 * m + 2) vs_frame_power_flush(*fp); /* (wave-uniform) */
+      }
+      if ((m & 3) == 3) {
+        vs_u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pk[e];
+        if (store_ok) *(vs_u32x4 *)(orow + n + 2 * m - 6) = v;
+      }
+    } else {
+      const int c0 = (o0 > 32767) ? 32767 : ((o0 < -32767) ? -32767 : o0), c1 = (o1 > 32767) ? 32767 : ((o1 < -32767) ? -32767 : o1);
+      if (store_ok && (n + 2 * m < N)) orow[n + 2 * m] = (int16_t)c0;
+      if (store_ok && (n + 2 * m + 1 < N)) orow[n + 2 * m + 1] = (int16_t)c1;
+    }
+  }
+}
+
 #endif

@@ -474,8 +474,14 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
   if (args.ws_filter_prio >= 3) __builtin_amdgcn_s_setprio(3);
   else if (args.ws_filter_prio == 2) __builtin_amdgcn_s_setprio(2);
   else if (args.ws_filter_prio == 1) __builtin_amdgcn_s_setprio(1);
+  /* VS_ARITH_F32: the window and the taps are the packed single-precision ones (VsF32Filter, vs_dev_filter.h); the double
+   * ones below are never touched and compile away */
+  constexpr bool F32 = (ARITH == VS_ARITH_F32);
+  constexpr int DARITH = F32 ? VS_ARITH_FMA : ARITH;
+  VsF32Filter f32;
   double a[VS_ORDER + 1];
-  vs_load_taps<ARITH>(args.taps, L, a);
+  if (F32) vs_f32_load(args.taps, L, f32);
+  else vs_load_taps<DARITH>(args.taps, L, a);
   const double gain = L->gain;
   const double pre = L->pre;
   int16_t *orow = args.out + g.row * args.out_pitch;
@@ -563,8 +569,11 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
         fp.len = f_len;
         fp.force = (args.fault == VS_FAULT_REROUND) && ((n / VS_SS) % 7 == 3);
       }
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL, POW>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                                      N, true, outv, xpre, true, &fp);
+      if constexpr (F32)
+        vs_superstep_f32<PRE1, 1, POW>(f32, ring + rslot * VS_WAVE + lane, orow, n, N, true, &fp);
+      else
+        vs_superstep<DARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL, POW>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                                         N, true, outv, xpre, true, &fp);
       if (POW) {
         if (fp.tb) { /* a frame ended behind sample tb - 1; the rest of the super-step went to the next one's sum */
           fp.frame += 1;
@@ -589,8 +598,11 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
       await(n);
       int outv[VS_SS];
       vs_u32x4 xpre[VS_SS / 8];
-      vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 0>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
-                                                        N, false, outv, xpre, true);
+      if constexpr (F32)
+        vs_superstep_f32<PRE1, 0, false>(f32, ring + rslot * VS_WAVE + lane, orow, n, N, true);
+      else
+        vs_superstep<DARITH, VS_KIND_SYNTH, PRE1, true, 0>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow, n,
+                                                           N, false, outv, xpre, true);
       release(n + VS_SS);
       VS_DIAG_ADD(dg, 0)
     }
@@ -624,15 +636,21 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
           if (ready) {
             int outv[VS_SS];
             vs_u32x4 xpre[VS_SS / 8]; /* only the filter-only kind prefetches */
-            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
-                                                                       n, N, true, outv, xpre);
+            if constexpr (F32)
+              vs_superstep_f32<PRE1, 1, false>(f32, ring + rslot * VS_WAVE + lane, orow, n, N, true);
+            else
+              vs_superstep<DARITH, VS_KIND_SYNTH, PRE1, true, 1, PARTIAL>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                                          n, N, true, outv, xpre);
           }
         } else {
           if (ready) {
             int outv[VS_SS];
             vs_u32x4 xpre[VS_SS / 8];
-            vs_superstep<ARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
-                                                           n, N, args.vec_ok != 0, outv, xpre);
+            if constexpr (F32)
+              vs_superstep_f32<PRE1, 0, false>(f32, ring + rslot * VS_WAVE + lane, orow, n, N, true);
+            else
+              vs_superstep<DARITH, VS_KIND_SYNTH, PRE1, true>(a, y, gain, pre, ring + rslot * VS_WAVE + lane, nullptr, orow,
+                                                              n, N, args.vec_ok != 0, outv, xpre);
           }
         }
         if (ready) {
@@ -1115,7 +1133,7 @@ extern "C" hipError_t vs_launch_filter_wide(int arith, const VsKernelArgs *args,
   if (!args->awide || !args->in) return hipErrorInvalidValue;
   if (arith == VS_ARITH_EXACT)
     hipLaunchKernelGGL(vs_filter_wide_kernel<VS_ARITH_EXACT>, dim3(grid), dim3(VS_WAVE), 0, stream, *args);
-  else
+  else /* (VS_ARITH_F32 as well: the single-precision filter is the wave-specialised kernels' alone) */
     hipLaunchKernelGGL(vs_filter_wide_kernel<VS_ARITH_FMA>, dim3(grid), dim3(VS_WAVE), 0, stream, *args);
   return hipGetLastError();
 }
@@ -1372,6 +1390,7 @@ static vs_kernel_fn vs_pick_ws2(bool three, bool pow)
 static vs_kernel_fn vs_pick_ws(int arith, bool pre1, bool three, bool pow)
 {
   if (arith == VS_ARITH_EXACT) return pre1 ? vs_pick_ws2<VS_ARITH_EXACT, true>(three, pow) : vs_pick_ws2<VS_ARITH_EXACT, false>(three, pow);
+  if (arith == VS_ARITH_F32) return pre1 ? vs_pick_ws2<VS_ARITH_F32, true>(three, pow) : vs_pick_ws2<VS_ARITH_F32, false>(three, pow);
   return pre1 ? vs_pick_ws2<VS_ARITH_FMA, true>(three, pow) : vs_pick_ws2<VS_ARITH_FMA, false>(three, pow);
 }
 extern "C" hipError_t vs_launch_kernel_narrow(int arith, int kind, bool log, bool pre1, const VsKernelArgs *args,
@@ -1411,16 +1430,19 @@ extern "C" hipError_t VS_LAUNCH_NAME(int arith, int kind, bool log, bool wave_sp
     if (!args->group_map) lds_bytes = (size_t)args->ws_pair_bytes * (size_t)args->ws_pairs;
     else if (args->ws_pairs != 4 || (three && args->ws_layout != VS_WS_LAYOUT_ROLE_MAJOR)) return hipErrorInvalidValue;
     grid = (grid + (unsigned)args->ws_pairs - 1) / (unsigned)args->ws_pairs;
-  } else
+  }
 #endif
-  if (arith == VS_ARITH_EXACT) {
-    if (kind == VS_KIND_SYNTH) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, true>(log) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, false>(log);
-    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
-    else if (kind == VS_KIND_FILTER) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, true>(false) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, false>(false);
-  } else if (arith == VS_ARITH_FMA) {
-    if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_SYNTH, false>(log);
-    else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
-    else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_FILTER, false>(false);
+  if (!fn) { /* the one-wave kernel */
+    if (arith == VS_ARITH_F32) arith = VS_ARITH_FMA; /* only the wave-specialised kernels have the single-precision filter */
+    if (arith == VS_ARITH_EXACT) {
+      if (kind == VS_KIND_SYNTH) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, true>(log) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_SYNTH, false>(log);
+      else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
+      else if (kind == VS_KIND_FILTER) fn = pre1 ? vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, true>(false) : vs_pick_log<VS_ARITH_EXACT, VS_KIND_FILTER, false>(false);
+    } else if (arith == VS_ARITH_FMA) {
+      if (kind == VS_KIND_SYNTH) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_SYNTH, false>(log);
+      else if (kind == VS_KIND_SOURCE) fn = vs_pick_log<VS_ARITH_EXACT, VS_KIND_SOURCE, false>(log);
+      else if (kind == VS_KIND_FILTER) fn = vs_pick_log<VS_ARITH_FMA, VS_KIND_FILTER, false>(false);
+    }
   }
   if (!fn) return hipErrorInvalidValue;
   if (kind == VS_KIND_FILTER) lds_bytes = 0;

@@ -54,6 +54,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "vs_commguard.h"
 #include "vs_internal.h"
 
 #define VS_NODE_CHUNK 16384
@@ -85,12 +86,13 @@ struct vs_node {
   int transport;                      /* VS_NODE_TRANSPORT_* */
   VsRccl rccl;
   int n_comm;                         /* communicators made (0 or n_shards), RCCL transport only */
-  vs_nccl_comm comm[VS_NODE_MAX_SHARDS]; /* one per shard (rank = shard); NULL once aborted */
-  /* every host call into RCCL on comm[s] -- the shard's ncclSend, the root's GroupStart .. GroupEnd, and the
-   * ncclCommAbort of a failing shard's thread -- is made under comm_m[s]: an abort can then never free a
-   * communicator another thread is inside of, and whoever comes after it finds NULL and stops */
-  pthread_mutex_t comm_m[VS_NODE_MAX_SHARDS];
-  bool comm_m_ready;
+  /* one communicator per shard (rank = shard), each behind a guard (csrc/vs_commguard.h): a host call into RCCL -- the
+   * shard's ncclSend, the root's GroupStart .. GroupEnd -- counts itself in and is made with NO lock held (it may block
+   * until the peer answers); the ncclCommAbort of a failing shard's thread marks the communicator dead first, so that
+   * nobody enters any more, aborts it -- which is what makes a blocked call return --, and forgets it once the callers
+   * have left */
+  VsCommGuard guard[VS_NODE_MAX_SHARDS];
+  bool guards_ready;
   void *rccl_lib_aborted;             /* librccl of an aborted exchange: kept open until vs_node_destroy (its proxy
                                          threads may still be winding down when the gather returns) */
   hipStream_t recv;                   /* on the root device: THE stream the root's receive groups are posted on */
@@ -104,8 +106,8 @@ int vs_node_create(const int *devices, int n_shards, vs_node **out)
   vs_node *nd = (vs_node *)calloc(1, sizeof(vs_node));
   if (!nd) return VS_ERR_NOMEM;
   nd->transport = VS_NODE_TRANSPORT_PEER;
-  for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) pthread_mutex_init(&nd->comm_m[s], NULL);
-  nd->comm_m_ready = true;
+  for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) vs_commguard_init(&nd->guard[s]);
+  nd->guards_ready = true;
   int rc = VS_OK;
   for (int s = 0; s < n_shards && rc == VS_OK; s++) {
     vs_ctx *c = NULL;
@@ -151,13 +153,11 @@ int vs_node_create(const int *devices, int n_shards, vs_node **out)
 static void vs_node_drop_rccl(vs_node *nd, bool keep_lib)
 {
   for (int s = 0; s < nd->n_comm; s++) {
-    pthread_mutex_lock(&nd->comm_m[s]);
-    if (nd->comm[s] && nd->rccl.CommDestroy) {
+    vs_nccl_comm c = vs_commguard_take(&nd->guard[s]); /* NULL: aborted (gone already), or never made */
+    if (c && nd->rccl.CommDestroy) {
       (void)hipSetDevice(nd->device[s]);
-      (void)nd->rccl.CommDestroy(nd->comm[s]);
+      (void)nd->rccl.CommDestroy(c);
     }
-    nd->comm[s] = NULL;
-    pthread_mutex_unlock(&nd->comm_m[s]);
   }
   nd->n_comm = 0;
   if (nd->recv) {
@@ -222,14 +222,16 @@ int vs_node_set_transport(vs_node *nd, int transport)
     vs_node_drop_rccl(nd, false);
     return VS_ERR_UNSUPPORTED;
   }
-  memset(nd->comm, 0, sizeof(nd->comm));
-  const int e = R->CommInitAll(nd->comm, S, nd->device);
+  vs_nccl_comm comms[VS_NODE_MAX_SHARDS];
+  memset(comms, 0, sizeof(comms));
+  const int e = R->CommInitAll(comms, S, nd->device);
   if (e != 0) {
     nd->last_rccl_error = e;
     nd->n_comm = 0;
     vs_node_drop_rccl(nd, false);
     return VS_ERR_HIP;
   }
+  for (int s = 0; s < S; s++) vs_commguard_set(&nd->guard[s], comms[s]);
   nd->n_comm = S;
   /* the root posts its receive groups on ONE stream of its own (concurrency inside a group of
    * point-to-point operations comes from RCCL's channels, not from streams) */
@@ -267,8 +269,8 @@ void vs_node_destroy(vs_node *nd)
     }
     vs_ctx_destroy(nd->ctx[s]);
   }
-  if (nd->comm_m_ready)
-    for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) pthread_mutex_destroy(&nd->comm_m[s]);
+  if (nd->guards_ready)
+    for (int s = 0; s < VS_NODE_MAX_SHARDS; s++) vs_commguard_destroy(&nd->guard[s]);
   free(nd);
 }
 
@@ -350,16 +352,12 @@ static void abort_exchange(vs_node *nd, GatherSync *sync)
 {
   pthread_mutex_lock(&sync->abort_m);
   if (!atomic_exchange(&sync->aborted, true) && nd->transport == VS_NODE_TRANSPORT_RCCL) {
-    for (int p = 0; p < nd->n_comm; p++) {
-      /* under the communicator's lock: no other thread is inside ncclSend / the root's receive group on it,
-       * and whoever takes the lock next finds NULL */
-      pthread_mutex_lock(&nd->comm_m[p]);
-      if (nd->comm[p]) {
-        (void)nd->rccl.CommAbort(nd->comm[p]);
-        nd->comm[p] = NULL;
-      }
-      pthread_mutex_unlock(&nd->comm_m[p]);
-    }
+    /* every communicator is closed before the first one is aborted: a thread that comes back from a call on one of
+     * them must not walk into the next.  The aborts themselves run with no lock of the guards held (vs_commguard_abort):
+     * a peer -- or the root -- may be blocked INSIDE ncclSend / its receive group, waiting for the side of the exchange
+     * the failed shard will never post, and ncclCommAbort is what brings it back */
+    for (int p = 0; p < nd->n_comm; p++) vs_commguard_close(&nd->guard[p]);
+    for (int p = 0; p < nd->n_comm; p++) (void)vs_commguard_abort(&nd->guard[p], nd->rccl.CommAbort);
   }
   pthread_mutex_unlock(&sync->abort_m);
 }
@@ -449,11 +447,11 @@ static void *shard_gather(void *arg)
       /* the chunk leaves by ncclSend behind its kernel; the root's thread posts the matching receive */
       e = hipStreamWaitEvent(nd->copy[s], nd->ev_done[k][s], 0);
       if (e == hipSuccess) {
-        pthread_mutex_lock(&nd->comm_m[s]);
-        const bool gone = nd->comm[s] == NULL; /* another shard failed and aborted the exchange: stop, no error of ours */
-        const int ne = gone ? 0 : nd->rccl.Send(P->d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, nd->comm[s], nd->copy[s]);
-        pthread_mutex_unlock(&nd->comm_m[s]);
-        if (gone) break;
+        vs_nccl_comm comm = vs_commguard_enter(&nd->guard[s]);
+        if (!comm) break; /* another shard failed and aborted the exchange: stop, no error of ours */
+        const int ne = nd->rccl.Send(P->d_out[k], rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, 0, comm, nd->copy[s]);
+        vs_commguard_leave(&nd->guard[s]);
+        if (ne != 0 && atomic_load(&sync->aborted)) break; /* ended by the abort of a failing shard, not a failure of this one */
         if (ne != 0) {
           nd->last_rccl_error = ne;
           j->rc = VS_ERR_HIP;
@@ -488,21 +486,19 @@ static void *shard_gather(void *arg)
      * one stream, straight into the peer's rows of the root buffer */
     const size_t rounds = vs_gather_rounds(j->n_total, S, VS_NODE_CHUNK);
     for (size_t kk = 0; kk < rounds && j->rc == VS_OK && !atomic_load(&sync->aborted); kk++) {
-      pthread_mutex_lock(&nd->comm_m[0]);
-      if (nd->comm[0] == NULL) { /* aborted by a failing shard between two rounds */
-        pthread_mutex_unlock(&nd->comm_m[0]);
-        break;
-      }
+      vs_nccl_comm comm0 = vs_commguard_enter(&nd->guard[0]);
+      if (!comm0) break; /* aborted by a failing shard between two rounds */
       int ne = nd->rccl.GroupStart();
       for (int p = 1; p < S && ne == 0; p++) {
         size_t r0 = 0, rows = 0;
         if (vs_gather_round(j->n_total, S, p, VS_NODE_CHUNK, kk, &r0, &rows) != VS_OK || rows == 0) continue;
         ne = nd->rccl.Recv(j->root + r0 * j->root_pitch, rows * j->n_samples * sizeof(int16_t), VS_NCCL_INT8, p,
-                           nd->comm[0], nd->recv);
+                           comm0, nd->recv);
       }
       const int ge = nd->rccl.GroupEnd();
-      pthread_mutex_unlock(&nd->comm_m[0]);
+      vs_commguard_leave(&nd->guard[0]);
       if (ne == 0) ne = ge;
+      if (ne != 0 && atomic_load(&sync->aborted)) break; /* ended by a failing shard's abort */
       if (ne != 0) {
         nd->last_rccl_error = ne;
         j->rc = VS_ERR_HIP;

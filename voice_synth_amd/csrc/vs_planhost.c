@@ -328,10 +328,8 @@ static void *team_worker(void *arg)
 {
   VsTeam *t = (VsTeam *)arg;
   unsigned seen = 0;
-  /* a library's helper threads take no part in the application's signal handling */
-  sigset_t all;
-  sigfillset(&all);
-  (void)pthread_sigmask(SIG_BLOCK, &all, NULL);
+  /* (a library's helper threads take no part in the application's signal handling: they are born with every signal
+   * blocked, team_create) */
   for (;;) {
     pthread_mutex_lock(&t->mu);
     while (t->gen == seen && !t->stop) pthread_cond_wait(&t->go, &t->mu);
@@ -357,10 +355,17 @@ static VsTeam *team_create(void)
   pthread_mutex_init(&t->mu, NULL);
   pthread_cond_init(&t->go, NULL);
   pthread_cond_init(&t->done, NULL);
+  /* a thread inherits the mask of the thread that makes it: every signal is blocked HERE, around pthread_create, and
+   * the caller's own mask put back behind it -- a mask set by the worker itself leaves a window in which a signal of the
+   * application's can still be delivered to it */
+  sigset_t all, mine;
+  sigfillset(&all);
+  const int masked = pthread_sigmask(SIG_BLOCK, &all, &mine) == 0;
   for (long k = 0; k + 1 < nt; k++) { /* a thread that cannot be started is simply not there */
     if (pthread_create(&t->th[t->n_workers], NULL, team_worker, t) != 0) break;
     t->n_workers++;
   }
+  if (masked) (void)pthread_sigmask(SIG_SETMASK, &mine, NULL);
   return t;
 }
 static void team_destroy(VsTeam *t)
@@ -404,7 +409,8 @@ struct VsPlanWs {
   VsTeam *team;      /* made with the first batch of VS_TEAM_MIN_LANES lanes or more */
   VsDevLane *rec[2]; /* the records in input order / in kernel order */
   size_t rec_lanes;  /* lanes either holds */
-  int rec_big;       /* the record buffers came from big_alloc (else malloc) */
+  int rec_big;       /* the record buffers are asked of big_alloc first (else malloc) */
+  int rec_from_big[2]; /* ... and where each one came from in the end: under page-locked-memory pressure either may be ordinary memory */
   vs_planws_alloc_fn big_alloc; /* where record buffers of VS_TEAM_MIN_LANES lanes and more come from (NULL: malloc) */
   vs_planws_free_fn big_free;
   void *big_user;
@@ -429,16 +435,27 @@ static void rec_release(VsPlanWs *ws)
 {
   for (int b = 0; b < 2; b++) {
     if (ws->rec[b]) {
-      if (ws->rec_big) ws->big_free(ws->big_user, ws->rec[b]);
+      if (ws->rec_from_big[b]) ws->big_free(ws->big_user, ws->rec[b]);
       else free(ws->rec[b]);
     }
     ws->rec[b] = NULL;
+    ws->rec_from_big[b] = 0;
   }
   ws->rec_lanes = 0;
 }
-static VsDevLane *rec_alloc(VsPlanWs *ws, size_t lanes)
+/* buffer b of the workspace: from the big allocator when the batch is big -- page-locked memory, so that the records' way
+ * to the device is a DMA transfer that runs NEXT TO a kernel instead of a copy kernel that waits for the chip to be free --
+ * and from malloc when there is none to be had (the upload is then staged by the runtime): either buffer, independently */
+static VsDevLane *rec_alloc(VsPlanWs *ws, int b, size_t lanes)
 {
-  return (VsDevLane *)(ws->rec_big ? ws->big_alloc(ws->big_user, lanes * sizeof(VsDevLane)) : malloc(lanes * sizeof(VsDevLane)));
+  VsDevLane *p = NULL;
+  ws->rec_from_big[b] = 0;
+  if (ws->rec_big) {
+    p = (VsDevLane *)ws->big_alloc(ws->big_user, lanes * sizeof(VsDevLane));
+    if (p) ws->rec_from_big[b] = 1;
+  }
+  if (!p) p = (VsDevLane *)malloc(lanes * sizeof(VsDevLane));
+  return p;
 }
 void vs_planws_destroy(VsPlanWs *ws)
 {
@@ -456,20 +473,14 @@ static int ws_reserve(VsPlanWs *ws, size_t n, int need_order)
 {
   if (ws->rec_lanes < n) {
     rec_release(ws);
-    /* big batches: from the context's allocator -- page-locked memory, so that the records' way to the device is a DMA
-     * transfer that runs NEXT TO a kernel instead of a copy kernel that waits for the chip to be free */
-    ws->rec_big = (ws->big_alloc != NULL) && n >= VS_TEAM_MIN_LANES;
-    ws->rec[0] = rec_alloc(ws, n);
-    if (!ws->rec[0] && ws->rec_big) { /* no page-locked memory to be had: ordinary memory (the upload is then staged by the runtime) */
-      ws->rec_big = 0;
-      ws->rec[0] = rec_alloc(ws, n);
-    }
+    ws->rec_big = (ws->big_alloc != NULL) && n >= VS_TEAM_MIN_LANES; /* big batches: from the context's allocator */
+    ws->rec[0] = rec_alloc(ws, 0, n);
     if (!ws->rec[0]) return VS_ERR_NOMEM;
     ws->rec_lanes = n;
   }
   if (need_order) {
     if (!ws->rec[1]) {
-      ws->rec[1] = rec_alloc(ws, ws->rec_lanes);
+      ws->rec[1] = rec_alloc(ws, 1, ws->rec_lanes);
       if (!ws->rec[1]) return VS_ERR_NOMEM;
     }
     if (ws->idx_lanes < n) {
