@@ -62,7 +62,7 @@ $(LIB): $(CSRC)/vs_host.o $(CSRC)/vs_planhost.o $(CSRC)/vs_kernels.o $(CSRC)/vs_
 clis: $(BINDIR)/flowgen_shimmer $(BINDIR)/vowel $(BINDIR)/vs_batch $(BINDIR)/vs_bench
 
 $(BINDIR)/%: $(PKG)/cli/%.c $(PKG)/cli/cli_common.h $(LIB) | $(BINDIR)
-	$(CC) -O2 -ffp-contract=off -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lvoicesynth -lm -Wl,-rpath,'$$ORIGIN/../lib'
+	$(CC) -O2 -ffp-contract=off -Wall -Iinclude -o $@ $< -L$(LIBDIR) -lvoicesynth -lm -lpthread -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle all

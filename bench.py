@@ -56,6 +56,7 @@ import argparse
 import json
 import os
 import socket
+import subprocess
 import sys
 import threading
 import time
@@ -672,6 +673,31 @@ def main():
         except Exception as exc:  # pragma: no cover - reported in the line
             fresh = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    # ---- the same from plain C, no Python in the loop (N = 1 only): cli/vs_bench.c --fresh -- 50 batches, the plan of batch
+    # k + 1 made on a second host thread while kernel k runs, plans of two batches ago destroyed meanwhile, device time from
+    # in front of the first launch to behind the last; and its steady-state loop (one plan, 50 launches) in the same process
+    # for the ratio.  A child process with its own HIP context, after this process's launches have drained.
+    fresh_c = None
+    if world == 1 and rank == 0 and not args.no_other_configs and args.config == 3 and not args.lanes:
+        try:
+            torch.cuda.synchronize(dev)
+            exe = os.path.join(ROOT, "voice_synth_amd", "bin", "vs_bench")
+            env = dict(os.environ, VS_DEVICE=str(dev.index or 0))
+            recs = []
+            for extra in ([], ["--fresh"]):
+                r = subprocess.run([exe, "--arith", args.arith, "--steps", "50", "--warmup", "10"] + extra, capture_output=True, timeout=300, env=env)
+                if r.returncode != 0:
+                    raise RuntimeError("vs_bench %s: %s" % (" ".join(extra), r.stderr.decode()[-300:]))
+                recs.append(json.loads(r.stdout.decode().strip().splitlines()[-1]))
+            fresh_c = {"ms_per_batch": recs[1]["ms_per_batch"], "Msamples/s": recs[1]["value"], "batches": recs[1]["batches"],
+                       "same_plan_ms_per_launch": recs[0]["ms_per_step"],
+                       "ratio_to_same_plan": round(recs[1]["ms_per_batch"] / recs[0]["ms_per_step"], 4),
+                       "plan_host_ms_avg": recs[1]["plan_host_ms_avg"], "plan_upload_ms_avg": recs[1]["plan_upload_ms_avg"],
+                       "plan_destroy_ms_avg": recs[1]["plan_destroy_ms_avg"],
+                       "last_batch_equals_a_plain_launch": recs[1]["last_batch_equals_a_plain_launch"], "how": recs[1]["how"]}
+        except Exception as exc:  # pragma: no cover - reported in the line
+            fresh_c = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     # ---- the other BASELINE configurations, outside the timed region (N = 1 only; at N > 1 the config-4 block below
     # is the second workload): configs 2, 4 (one GPU's shard of the 8-GPU cut) and 5, each launched a few times with
     # HIP events around every launch, in both arithmetic contracts -- so that the driver's line carries every
@@ -782,6 +808,7 @@ def main():
             "row_pitch_ab": pitch_ab,
             "other_configs": other_configs,
             "fresh_batches": fresh,
+            "fresh_batches_c": fresh_c,
             "plan": {"host_ms": round(plan_host_ms, 2), "upload_ms": round(plan_upload_ms, 2),
                      "note": "vs_plan_create of the per-GPU batch: validation + parameter expansion on host threads, "
                              "sort, cos rows; allocation + upload + wait.  Outside every timed region."},

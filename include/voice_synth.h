@@ -11,9 +11,15 @@
  * the reference lines it replaces.  Plain C types only: pointers, sizes, fixed-width
  * integers.  No function calls exit(); every failure is a negative return code.
  *
- * Threading: a vs_ctx and the plans made from it may be used by one thread at a time.
- * Different contexts are independent.  There is no global mutable state, and the library
- * reads no environment variable after vs_ctx_create() (see vs_ctx_set_tuning()).
+ * Threading: a vs_ctx and the plans made from it may be used by one thread at a time -- with one
+ * exception, made for callers who synthesise batch after batch of NEW utterances: while one thread
+ * launches, reseeds, waits and times (vs_plan_launch, vs_plan_reseed, vs_plan_status, vs_ctx_synchronize,
+ * vs_ctx_timer_*), ONE other thread may be inside vs_plan_create() or vs_plan_destroy() of the same
+ * context -- plan creation touches nothing a launch reads, works on host threads and a stream of its
+ * own, and the plan it returns is complete (cli/vs_bench.c --fresh does exactly that: the plan of
+ * batch k + 1 is made while kernel k runs).  Different contexts are independent.  There is no global
+ * mutable state, and the library reads no environment variable after vs_ctx_create() (see
+ * vs_ctx_set_tuning()).
  *
  * There is no CPU fallback: if no gfx950 device is usable, vs_ctx_create() fails with
  * VS_ERR_NODEVICE and nothing can be synthesised.
@@ -292,6 +298,11 @@ int vs_plan_launch(vs_plan *plan, int kind, const int16_t *in_dev, size_t in_pit
                    int16_t *out_dev, size_t out_pitch, vs_cycle_rec *log_dev, size_t log_pitch,
                    int32_t *ncyc_dev);
 int vs_ctx_synchronize(vs_ctx *ctx);
+/* Device time between two points of the context's launch stream, for callers who have no HIP of their own (the C programs
+ * of this package): vs_ctx_timer_mark(ctx, 0) and (ctx, 1) record an event each behind what has been enqueued so far;
+ * vs_ctx_timer_elapsed waits for mark 1 and gives the milliseconds from mark 0 to it. */
+int vs_ctx_timer_mark(vs_ctx *ctx, int which);
+int vs_ctx_timer_elapsed(vs_ctx *ctx, double *ms);
 /* Waits for the context's stream, then reports the health word of the plan's launches:
  * VS_OK, or VS_ERR_INTERNAL if a device-side check failed (*flags, optional, gets the raw bits:
  * 1, 2, 4 = a bounded wait of the generator / filter / noise wavefront ran out, 8 = plan and kernel

@@ -138,6 +138,16 @@ def test_vs_bench_runs_from_plain_c():
         assert r.returncode == 0, r.stderr
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
         assert d["utterances"] == 4096 and d["samples_per_utterance"] == 16000 and d["value"] > 100
+    # a plan per batch of new utterances, made on a second host thread next to the running kernel, the plans of two batches
+    # ago taken down meanwhile (their device blocks go to the plans to come): device time per batch, and the last batch's
+    # PCM equals a plain launch of the same utterances
+    for lanes, extra in ((4096, []), (70000, ["--arith", "fma"])):
+        r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", str(lanes), "--steps", "12", "--warmup", "1", "--fresh"] + extra,
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert d["batches"] == 12 and d["utterances_per_batch"] == lanes and d["ms_per_batch"] > 0 and d["value"] > 100
+        assert d["last_batch_equals_a_plain_launch"] is True and d["plan_destroy_ms_avg"] < 1.0 and d["plan_create_wall_ms_avg"] > 0
     # the node entry over two logical shards of the one device
     r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "2", "--warmup", "1", "--gpus", "2"],
                        capture_output=True, timeout=300, env=dict(os.environ, VS_DEVICES="0,0"))

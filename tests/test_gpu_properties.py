@@ -477,3 +477,39 @@ def test_shape_fuzz_small_draw():
         assert shape_fuzz.main() == 0
     finally:
         sys.argv = old
+
+
+def test_blocks_of_a_destroyed_plan_are_not_reused_before_its_launches_are_over():
+    """vs_plan_destroy hands a plan's device blocks to the context's cache (hipFree would wait for the whole device, every
+    batch: cli/vs_bench.c --fresh) and the next plan of that size takes them over -- behind an event recorded on the stream
+    of the old plan's last launch.  A plan destroyed while its kernel is still running, and a successor made at once from
+    its blocks with DIFFERENT utterances: both launches give what the oracle gives, again and again; vs_ctx_trim empties
+    the cache"""
+    eng = vs.Engine(0)
+    n, ns = 16384, 16000
+    outs = [eng.dev_alloc(n * ns * 2) for _ in range(2)]
+    try:
+        batches = []
+        for b in range(6):
+            specs, fs, dur, _ = configs.config_specs(3 if b % 2 == 0 else 5, n, lane0=1000 * b, seed0=77 + b)
+            batches.append(vs.lanes_from_specs(specs)[0])
+        for b, lanes in enumerate(batches):
+            plan = eng.plan(lanes, ns)                 # (from b = 1 on: made from blocks the plan before has just given back)
+            plan.launch(vs.VS_KIND_SYNTH, outs[b % 2])
+            plan.close()                               # ... while its kernel runs
+            if b >= 1:
+                eng.synchronize()
+                for k in (b - 1, b):
+                    got = eng.dev_download(outs[k % 2], (n, ns), np.int16)
+                    rows = np.arange(0, n, 37)
+                    assert np.array_equal(got[rows], po.synth([batches[k][int(i)] for i in rows], ns, threads=32)), (b, k)
+        assert vs.load().vs_ctx_trim(eng._ctx) == 0
+        plan = eng.plan(batches[0], ns)
+        plan.launch(vs.VS_KIND_SYNTH, outs[0])
+        eng.synchronize()
+        assert plan.status() == 0
+        plan.close()
+    finally:
+        for o in outs:
+            eng.dev_free(o)
+        eng.close()

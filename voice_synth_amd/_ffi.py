@@ -194,6 +194,8 @@ SYMBOLS = {
         [_vp, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_size_t, _vp],
     ),
     "vs_ctx_synchronize": (C.c_int, [_vp]),
+    "vs_ctx_timer_mark": (C.c_int, [_vp, C.c_int]),
+    "vs_ctx_timer_elapsed": (C.c_int, [_vp, _P(C.c_double)]),
     "vs_plan_status": (C.c_int, [_vp, _P(C.c_int)]),
     "vs_plan_reseed": (C.c_int, [_vp, _vp, _vp]),
     "vs_plan_info": (C.c_int, [_vp, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t)]),

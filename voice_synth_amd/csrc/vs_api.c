@@ -141,6 +141,9 @@ void vs_ctx_destroy(vs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamDestroy(ctx->own_upload);
   }
+  vs_plan_cache_release(ctx);
+  for (int k = 0; k < 2; k++)
+    if (ctx->timer[k]) (void)hipEventDestroy(ctx->timer[k]);
   vs_planws_destroy(ctx->planws);
   if (ctx->plan_pin) (void)hipHostFree(ctx->plan_pin);
   free(ctx);
@@ -184,6 +187,26 @@ int vs_ctx_synchronize(vs_ctx *ctx)
   if (!ctx) return VS_ERR_ARG;
   VS_HIP(ctx, hipSetDevice(ctx->device));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return VS_OK;
+}
+
+int vs_ctx_timer_mark(vs_ctx *ctx, int which)
+{
+  if (!ctx || (which != 0 && which != 1)) return VS_ERR_ARG;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->timer[which]) VS_HIP(ctx, hipEventCreate(&ctx->timer[which]));
+  VS_HIP(ctx, hipEventRecord(ctx->timer[which], ctx->stream));
+  return VS_OK;
+}
+
+int vs_ctx_timer_elapsed(vs_ctx *ctx, double *ms)
+{
+  if (!ctx || !ms || !ctx->timer[0] || !ctx->timer[1]) return VS_ERR_ARG;
+  float f = 0.0f;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_HIP(ctx, hipEventSynchronize(ctx->timer[1]));
+  VS_HIP(ctx, hipEventElapsedTime(&f, ctx->timer[0], ctx->timer[1]));
+  *ms = (double)f;
   return VS_OK;
 }
 
@@ -329,6 +352,86 @@ static void plan_pinned_free(void *user, void *ptr)
 {
   (void)user;
   if (ptr) (void)hipHostFree(ptr);
+}
+
+static void retire_unref(VsRetire *r)
+{
+  if (r && --r->refs == 0) {
+    (void)hipEventDestroy(r->ev);
+    free(r);
+  }
+}
+/* A device block of at least `bytes` for a plan: a retired one of a fitting size (at most twice what is asked for -- a
+ * plan of 64 utterances does not sit on the 8 MB of a batch's records) once the launches that read it are over, or a new
+ * one.  *cap = what it really holds. */
+static hipError_t plan_block_get(vs_ctx *ctx, size_t bytes, void **ptr, size_t *cap)
+{
+  if (bytes == 0) bytes = 1;
+  /* of the fitting blocks the one that has been retired longest: its launches are most likely over already (the block of
+   * the plan destroyed a moment ago would make this call wait for a kernel that has only just started) */
+  int best = -1;
+  for (int k = 0; k < VS_PLAN_CACHE_SLOTS; k++) {
+    const VsBlock *b = &ctx->plan_cache[k];
+    if (b->ptr && b->bytes >= bytes && b->bytes <= 2 * bytes + 4096 && (best < 0 || b->stamp < ctx->plan_cache[best].stamp)) best = k;
+  }
+  if (best >= 0) {
+    VsBlock *b = &ctx->plan_cache[best];
+    hipError_t e = b->retired ? hipEventSynchronize(b->retired->ev) : hipSuccess;
+    retire_unref(b->retired);
+    *ptr = b->ptr;
+    *cap = b->bytes;
+    b->ptr = NULL;
+    b->retired = NULL;
+    if (e == hipSuccess) return hipSuccess;
+    (void)hipFree(*ptr); /* cannot tell whether it is still read: not ours to hand on */
+    (void)hipGetLastError();
+  }
+  *cap = bytes;
+  return hipMalloc(ptr, bytes);
+}
+/* ... and back, when its plan is destroyed: behind the plan's last launch (retire: shared by the plan's blocks, NULL if it
+ * was never launched).  A full cache gives up its oldest block (hipFree: that one wait for the device is the price of the
+ * 33rd retired block). */
+static void plan_block_put(vs_ctx *ctx, void *ptr, size_t cap, VsRetire *retire)
+{
+  if (!ptr) return;
+  int slot = -1, oldest = 0;
+  for (int k = 0; k < VS_PLAN_CACHE_SLOTS; k++) {
+    if (!ctx->plan_cache[k].ptr) {
+      slot = k;
+      break;
+    }
+    if (ctx->plan_cache[k].stamp < ctx->plan_cache[oldest].stamp) oldest = k;
+  }
+  if (slot < 0) {
+    VsBlock *b = &ctx->plan_cache[oldest];
+    retire_unref(b->retired);
+    (void)hipFree(b->ptr);
+    b->ptr = NULL;
+    slot = oldest;
+  }
+  VsBlock *b = &ctx->plan_cache[slot];
+  if (cap == 0) {
+    (void)hipFree(ptr);
+    return;
+  }
+  b->ptr = ptr;
+  b->bytes = cap;
+  b->retired = retire;
+  if (retire) retire->refs++;
+  b->stamp = ++ctx->plan_cache_stamp;
+}
+void vs_plan_cache_release(vs_ctx *ctx)
+{
+  (void)hipSetDevice(ctx->device);
+  for (int k = 0; k < VS_PLAN_CACHE_SLOTS; k++) {
+    VsBlock *b = &ctx->plan_cache[k];
+    if (!b->ptr) continue;
+    retire_unref(b->retired);
+    (void)hipFree(b->ptr);
+    b->ptr = NULL;
+    b->retired = NULL;
+  }
 }
 
 int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
@@ -707,13 +810,13 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
       p->d_taps = p->d_costab + taps_off;
     }
   } else {
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_lanes, n_lanes * sizeof(VsDevLane));
+    if (e == hipSuccess) e = plan_block_get(ctx, n_lanes * sizeof(VsDevLane), (void **)&p->d_lanes, &p->cap_lanes);
     /* the small parts -- cos rows + tap table, the mixed-rings table, the error word -- share ONE device block that is
      * never smaller than VS_SMALL_BLOCK_MIN and goes up in ONE copy: the runtime moves copies of up to 16 KiB with a
      * kernel of its own, and that kernel waits until the chip has room, i.e. until a fused launch that is running has
      * ENDED (it fills every CU for its whole duration), while a copy of 64 KiB is a DMA transfer that runs next to it --
      * 0.03 ms instead of 2.2 behind a launch (tools/overlap_probe.py, profiles/r05_plan_cost.txt) */
-    if (e == hipSuccess) e = hipMalloc((void **)&p->d_small, small_alloc);
+    if (e == hipSuccess) e = plan_block_get(ctx, small_alloc, (void **)&p->d_small, &p->cap_small);
     if (e == hipSuccess) {
       p->d_costab = (double *)p->d_small;
       p->d_err = (int *)(p->d_small + small_off_err);
@@ -722,11 +825,11 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
     if (e == hipSuccess && wide) e = hipMalloc((void **)&p->d_awide, n_lanes * (size_t)VS_WIDE_ORDER * sizeof(double));
     if (e == hipSuccess) p->d_taps = p->d_costab + taps_off;
   }
-  if (e == hipSuccess && wave_specialised) e = hipMalloc((void **)&p->d_sink, (n_samples + 32) * sizeof(int16_t));
+  if (e == hipSuccess && wave_specialised) e = plan_block_get(ctx, (n_samples + 32) * sizeof(int16_t), (void **)&p->d_sink, &p->cap_sink);
   if (e == hipSuccess && gmap && zero_copy) e = hipMalloc((void **)&p->d_group_map, n_wg_mixed * 4 * sizeof(VsGroupSlot));
   if (e == hipSuccess && p->ondw_pitch)
-    e = hipMalloc((void **)&p->d_ondw, n_lanes * (size_t)p->ondw_pitch * sizeof(float));
-  if (e == hipSuccess && p->pow_lframe) e = hipMalloc((void **)&p->d_odone, n_lanes * sizeof(int32_t));
+    e = plan_block_get(ctx, n_lanes * (size_t)p->ondw_pitch * sizeof(float), (void **)&p->d_ondw, &p->cap_ondw);
+  if (e == hipSuccess && p->pow_lframe) e = plan_block_get(ctx, n_lanes * sizeof(int32_t), (void **)&p->d_odone, &p->cap_odone);
   if (e == hipSuccess && wide && !filter_only) {
     const size_t flow_bytes = n_lanes * p->flow_pitch * sizeof(int16_t);
     if (mode & VS_PLAN_POOL_SCRATCH) {
@@ -807,22 +910,46 @@ void vs_plan_destroy(vs_plan *p)
 {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
+  /* the blocks every plan has go back to the context's cache, behind the launches that still read them (no hipFree, which
+   * would wait for the device: plan_block_put); the rare ones are freed */
+  vs_ctx *ctx = p->ctx;
+  VsRetire *retire = NULL;
+  if (p->last_launch) {
+    retire = (VsRetire *)malloc(sizeof(VsRetire));
+    if (retire) {
+      retire->ev = p->last_launch;
+      retire->refs = 1; /* ours, until the blocks have theirs */
+    } else { /* no memory for 16 bytes: wait here instead */
+      (void)hipEventSynchronize(p->last_launch);
+      (void)hipEventDestroy(p->last_launch);
+    }
+  }
   if (p->zc_host) {
     (void)hipHostFree(p->zc_host); /* records, cos rows, error word and wide taps of a zero-copy plan */
   } else {
-    if (p->d_lanes) (void)hipFree(p->d_lanes);
-    if (p->d_small) (void)hipFree(p->d_small); /* cos rows + taps, the mixed-rings table, the error word */
+    plan_block_put(ctx, p->d_lanes, p->cap_lanes, retire);
+    plan_block_put(ctx, p->d_small, p->cap_small, retire); /* cos rows + taps, the mixed-rings table, the error word */
     if (p->d_awide) (void)hipFree(p->d_awide);
   }
-  if (p->d_sink) (void)hipFree(p->d_sink);
+  plan_block_put(ctx, p->d_sink, p->cap_sink, retire);
   if (p->d_seeds) (void)hipFree(p->d_seeds);
   if (p->h_seeds) (void)hipHostFree(p->h_seeds);
   if (p->seeds_copied) (void)hipEventDestroy(p->seeds_copied);
   if (p->d_group_map && !p->d_small) (void)hipFree(p->d_group_map); /* (inside d_small when the plan copies) */
-  if (p->d_ondw) (void)hipFree(p->d_ondw);
-  if (p->d_odone) (void)hipFree(p->d_odone);
+  plan_block_put(ctx, p->d_ondw, p->cap_ondw, retire);
+  plan_block_put(ctx, p->d_odone, p->cap_odone, retire);
   if (p->d_flow && p->owns_flow) (void)hipFree(p->d_flow);
+  retire_unref(retire);
   free(p);
+}
+
+/* behind every launch of a plan: the event its device blocks will retire behind (plan_block_put) */
+static int plan_mark_launch(vs_plan *p)
+{
+  vs_ctx *ctx = p->ctx;
+  if (!p->last_launch) VS_HIP(ctx, hipEventCreateWithFlags(&p->last_launch, hipEventDisableTiming));
+  VS_HIP(ctx, hipEventRecord(p->last_launch, ctx->stream));
+  return VS_OK;
 }
 
 int vs_plan_status(vs_plan *p, int *flags)
@@ -877,7 +1004,7 @@ int vs_plan_reseed(vs_plan *p, const uint64_t *seeds, const uint64_t *out_seeds)
   VS_HIP(ctx, hipMemcpyAsync(p->d_seeds, p->h_seeds, 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
   VS_HIP(ctx, hipEventRecord(p->seeds_copied, ctx->stream));
   VS_HIP(ctx, vs_launch_reseed(p->d_lanes, p->d_seeds, p->d_seeds + n, (int)n, ctx->stream));
-  return VS_OK;
+  return plan_mark_launch(p); /* (the reseed kernel writes the records: the blocks retire behind it) */
 }
 
 /* diagnostic builds (tools/diag_bench.py): device buffer of grid*8 uint64 cycle counters */
@@ -1042,6 +1169,6 @@ int vs_plan_launch(vs_plan *p, int kind, const int16_t *in_dev, size_t in_pitch,
   }
   /* vowel -n (vowel_new.c:302-324): two streaming passes over the finished PCM -- every frame's power, then the noise */
   if (a.ondw) VS_HIP(ctx, vs_launch_out_noise(&a, ctx->stream));
-  return VS_OK;
+  return plan_mark_launch(p);
 }
 

@@ -108,6 +108,7 @@ int vs_ctx_trim(vs_ctx *ctx)
 {
   if (!ctx) return VS_ERR_ARG;
   vs_pool_release(ctx);
+  vs_plan_cache_release(ctx);
   return VS_OK;
 }
 

@@ -9,6 +9,7 @@
 #define VS_INTERNAL_H
 
 #include <hip/hip_runtime_api.h>
+#include <stdatomic.h>
 #include <stdbool.h>
 
 #include "../../include/voice_synth.h"
@@ -40,6 +41,24 @@ typedef struct VsPool {
   size_t zc_io_bytes;       /* cycle log and counts in ONE block of pinned, device-mapped host memory -- no copy at all */
 } VsPool;
 
+/* Device blocks of plans that have been destroyed, kept for the plans to come: a caller who synthesises batch after batch
+ * of new utterances makes and destroys a plan per batch, and hipFree waits for the DEVICE -- for the kernels of the batches
+ * behind, which have nothing to do with the block (cli/vs_bench.c --fresh: 4.3 ms per batch where the kernel takes 2.5).
+ * A retired block carries the event its plan recorded behind its last launch (vs_plan_launch re-records it every time: a
+ * few microseconds); the plan that takes the block over waits for THAT -- the one kernel that read the block -- not for
+ * the device, and not for whatever else the stream has taken on since. */
+#define VS_PLAN_CACHE_SLOTS 32
+typedef struct VsRetire { /* shared by the blocks of one destroyed plan */
+  hipEvent_t ev;          /* recorded behind the plan's LAST launch, when that launch was enqueued */
+  int refs;
+} VsRetire;
+typedef struct VsBlock {
+  void *ptr;
+  size_t bytes;
+  VsRetire *retired;   /* NULL: the plan was never launched */
+  unsigned long stamp; /* age: the oldest goes when the cache is full */
+} VsBlock;
+
 struct vs_ctx {
   int device;
   int arith;
@@ -48,7 +67,7 @@ struct vs_ctx {
   hipStream_t own_upload; /* ... else on this one, created with the first plan that copies: NEVER on `stream`, where the
                              copy would queue behind whatever kernel the caller has running there -- a caller who makes
                              batch k + 1's plan while batch k's kernel runs would wait for that kernel in vs_plan_create */
-  int last_hip_error;
+  _Atomic int last_hip_error; /* (the one word both halves of a pipelining caller may write: include/voice_synth.h, "Threading") */
   char name[128];
   int cu_count;
   vs_tuning tuning; /* all zero = the library's own choices */
@@ -56,6 +75,9 @@ struct vs_ctx {
   void *plan_pin;          /* page-locked host block the small parts of a plan go up from (cos rows + taps, group table, the zero word) */
   size_t plan_pin_bytes;
   struct VsPlanWs *planws; /* plan creation's worker threads and host buffers between calls (csrc/vs_planhost.c; a context is used by one thread at a time) */
+  hipEvent_t timer[2];    /* vs_ctx_timer_mark: made on first use */
+  VsBlock plan_cache[VS_PLAN_CACHE_SLOTS]; /* touched by vs_plan_create / vs_plan_destroy only (one thread at a time) */
+  unsigned long plan_cache_stamp;
   int copy_warm;          /* the runtime's copy path has been set up (vs_copy_path_warm) */
   double copy_warm_ms;    /* ... and what that cost */
   /* where the hardware deals the wavefronts of a workgroup (vs_ctx_simd_dealing): asked once, the first time a
@@ -74,6 +96,8 @@ struct vs_plan {
   vs_ctx *ctx;
   size_t n_lanes, n_samples;
   VsDevLane *d_lanes;
+  hipEvent_t last_launch;   /* recorded behind every launch (and reseed) of this plan; NULL until the first: what its blocks retire behind */
+  size_t cap_lanes, cap_small, cap_sink, cap_ondw, cap_odone; /* what the blocks below really hold (they may come from the context's cache of retired blocks) */
   char *d_small;     /* plans that copy: ONE device block for cos rows + taps, the mixed-rings table and the error word (d_costab, d_group_map, d_err point into it) */
   double *d_costab;
   double *d_taps;    /* the tap table: [rows][22] (rows 0..9 the ten tables, then the lanes' own sets) */
@@ -174,5 +198,7 @@ int vs_pool_device(vs_ctx *ctx, void **ptr, size_t *have, size_t bytes);
 /* creates the delivery streams, events and pinned staging buffers (at least row_bytes each) on first use */
 int vs_pool_streams(vs_ctx *ctx, size_t row_bytes);
 void vs_pool_release(vs_ctx *ctx);
+/* the cache of retired plan blocks (csrc/vs_api.c): hipFree of all of them */
+void vs_plan_cache_release(vs_ctx *ctx);
 
 #endif
