@@ -84,7 +84,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json configuration (1-based), default 3")
     ap.add_argument("--lanes", type=int, default=0, help="utterances per GPU (default: the configuration's batch)")
-    ap.add_argument("--arith", choices=["exact", "fma"], default="exact")
+    ap.add_argument("--arith", choices=["exact", "fma", "f32"], default="exact",
+                    help="exact (default: the reference's rounding sequence); fma and f32 are the opt-in tolerance modes")
+    ap.add_argument("--vowel-n", type=float, default=None, metavar="DB",
+                    help="every utterance also asks the vowel stage for its own noise (vowel -n DB): not a BASELINE workload, for profiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dense-rows", action="store_true", help="PCM rows only rounded up to 16 bytes instead of the pitch vs_row_pitch() names")
     ap.add_argument("--no-gather", action="store_true")
@@ -384,11 +387,16 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
             avg = sum(ms) / len(ms)
             recs.append({"workload": label, "baseline_config_index": cfg_i - 1, "utterances": n_lanes, "samples_per_utterance": ns,
                          "row_pitch_samples": pitch,
-                         "arith": "exact" if ar == vs.VS_ARITH_EXACT else "fma",
+                         "arith": {vs.VS_ARITH_EXACT: "exact", vs.VS_ARITH_FMA: "fma", vs.VS_ARITH_F32: "f32"}[ar],
                          "kernel": plan.kernel_name(vs.VS_KIND_SYNTH), "launches": launches,
                          "kernel_ms_avg": round(avg, 4), "kernel_ms_min": round(ms[0], 4),
                          "Msamples/s": round(n_lanes * ns / (avg * 1e-3) / 1e6, 1),
                          "roofline_frac": round(ALGO_BYTES_PER_SAMPLE * n_lanes * ns / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+            try:
+                cus_ = eng.device_info()[1]
+                recs[-1]["profile"] = _config_profile(cfg_i, recs[-1]["arith"], n_lanes, out_noise_db, recs[-1]["kernel"], avg, cus_, ns)
+            except Exception as exc:  # pragma: no cover
+                recs[-1]["profile"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             if out_noise_db is not None:
                 recs[-1].update({"vowel_n_db": out_noise_db, "bytes_per_sample": 6,
                                  "hbm_frac_at_6_bytes": round(6 * n_lanes * ns / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
@@ -397,6 +405,33 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
         plan.close()
         torch.cuda.empty_cache()
     return recs
+
+
+def _config_profile(cfg_i, arith_name, n_lanes, out_noise_db, kernel_name, kernel_ms, cus, n_samples):
+    """What profiles/pmc_*.json hold for one of the other configurations: HBM bytes per launch and the vector-pipe bound,
+    each only if the record was taken on THIS tree's kernel sources (else null, like the headline's)."""
+    key = "config%d%s%s_%s_%d" % (cfg_i, "_shard" if cfg_i == 4 else "", "_onoise" if out_noise_db is not None else "", arith_name, n_lanes)
+    rec = _profile_record("pmc_traffic.json", key)
+    sq = _profile_record("pmc_valu.json", key)
+    prov = _profile_provenance(rec, sq)
+    first = kernel_name.split(" + ")[0]
+    if rec and not (prov["traffic"]["matches_tree"] and first in str(rec.get("kernel", ""))):
+        rec = None
+    if sq and not (prov["valu"]["matches_tree"] and first in str(sq.get("kernel", ""))):
+        sq = None
+    out = {"profile_key": key, "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+           "traffic_matches_tree": bool(prov["traffic"] and prov["traffic"]["matches_tree"]),
+           "valu_matches_tree": bool(prov["valu"] and prov["valu"]["matches_tree"])}
+    if rec:
+        out["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / (ALGO_BYTES_PER_SAMPLE * n_lanes * n_samples), 4)
+    if sq:
+        wi, clk = sq["SQ_INSTS_VALU_per_launch"], sq.get("clock_GHz_under_profiler")
+        out["valu_wave_instructions_per_sample"] = round(wi / (n_lanes * n_samples / 64.0), 2)
+        if clk:
+            pipe_ms = wi * 4.0 / (4.0 * cus) / (clk * 1e9) * 1e3
+            out["pipe_bound_ms"] = round(pipe_ms, 4)
+            out["frac_of_pipe_bound"] = round(pipe_ms / kernel_ms, 4)
+    return out
 
 
 def _profile_record(name, key):
@@ -422,6 +457,22 @@ def _profile_provenance(traffic_rec, valu_rec):
                                           "kernel_sources_sha16": rec.get("kernel_sources_sha16"),
                                           "matches_tree": rec.get("kernel_sources_sha16") == tree}
     return out
+
+
+def preflight_errors(ranks_seen, world):
+    """What is wrong with a node run before anything is timed: [] or the findings -- N ranks must drive N DIFFERENT devices
+    (host + PCI bus id), over RCCL, each in a communicator of all N."""
+    wrong = []
+    distinct = len({(r_["host"], r_["pci_bus_id"]) for r_ in ranks_seen})
+    if len(ranks_seen) != world:
+        wrong.append("%d ranks reported, expected %d" % (len(ranks_seen), world))
+    if distinct != world:
+        wrong.append("%d ranks drive %d distinct devices" % (world, distinct))
+    if any(r_.get("comm_world_size") != world for r_ in ranks_seen):
+        wrong.append("communicator sizes %s, expected %d" % ([r_.get("comm_world_size") for r_ in ranks_seen], world))
+    if any(r_.get("backend") != "nccl" for r_ in ranks_seen):
+        wrong.append("backends %s, expected nccl (= RCCL)" % sorted({str(r_.get("backend")) for r_ in ranks_seen}))
+    return wrong
 
 
 def _free_port():
@@ -490,7 +541,7 @@ def main():
     full = {1: 1, 2: 1024, 3: 65536, 4: 262144 // 8, 5: 65536}[args.config]
     per_gpu = args.lanes or full
     lane0 = rank * per_gpu
-    specs, fs, dur, label = configs.config_specs(args.config, per_gpu, lane0=lane0)
+    specs, fs, dur, label = configs.config_specs(args.config, per_gpu, lane0=lane0, out_noise_db=args.vowel_n)
     lanes, d = vs.lanes_from_specs(specs)
     n_samples = vs.num_samples(fs, d)
     # the PCM buffer is the caller's: rows of n_samples at the pitch vs_row_pitch() names (include/voice_synth.h: a whole
@@ -499,19 +550,34 @@ def main():
     dense_pitch = (n_samples + 7) & ~7
     pitch = dense_pitch if args.dense_rows else vs.row_pitch(n_samples)
 
-    arith = vs.VS_ARITH_EXACT if args.arith == "exact" else vs.VS_ARITH_FMA
+    arith = {"exact": vs.VS_ARITH_EXACT, "fma": vs.VS_ARITH_FMA, "f32": vs.VS_ARITH_F32}[args.arith]
     stream = torch.cuda.current_stream(dev)
     eng = vs.Engine(local_rank, arith=arith, stream=stream.cuda_stream)
     dev_name, cus = eng.device_info()
     # which device every rank really drives: a scaling curve is only one if N DIFFERENT devices took part
     ident = {"rank": rank, "local_rank": local_rank, "device_index": torch.cuda.current_device(), "pci_bus_id": eng.device_pci(),
-             "host": socket.gethostname()}
+             "host": socket.gethostname(), "backend": dist.get_backend() if use_dist else None,
+             "comm_world_size": dist.get_world_size() if use_dist else 1}
     ranks_seen = [ident]
     if use_dist:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, ident)
         ranks_seen.sort(key=lambda r_: r_["rank"])
     distinct_devices = len({(r_["host"], r_["pci_bus_id"]) for r_ in ranks_seen})
+    # Pre-flight of a node run (the first real 8-GPU run is the driver's, unattended): N ranks must drive N DIFFERENT
+    # devices and every rank's communicator must be RCCL over all N of them -- a mis-bound launch (two ranks on one card, a
+    # rank that came up on gloo) would still print a curve.  Outside the one-GPU rehearsals of the tests it is an error:
+    # rank 0 prints the line with it, every rank leaves with a non-zero code, nothing is timed.
+    if world > 1 and not rehearsal:
+        wrong = preflight_errors(ranks_seen, world)
+        if wrong:
+            if rank == 0:
+                print(json.dumps({"metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref", "value": None,
+                                  "unit": "Msamples/s", "n_gpus": world, "error": "pre-flight: " + "; ".join(wrong),
+                                  "ranks_seen": ranks_seen, "distinct_devices": distinct_devices}), flush=True)
+            eng.close()
+            dist.destroy_process_group()
+            sys.exit(5)
     plan = eng.plan(lanes, n_samples)                     # lane records + cos rows -> HBM
     plan_host_ms, plan_upload_ms = plan.timing()
     kernel_name = plan.kernel_name(vs.VS_KIND_SYNTH)
@@ -715,7 +781,8 @@ def main():
     result = None
     if rank == 0:
         achieved = ALGO_BYTES_PER_SAMPLE * per_gpu * n_samples / (kern_ms_avg * 1e-3) / 1e9
-        key = "config%d_%s_%d" % (args.config, args.arith, per_gpu)
+        key = "config%d%s%s_%s_%d" % (args.config, "_shard" if args.config == 4 else "", "_onoise" if args.vowel_n is not None else "",
+                                        args.arith, per_gpu)
         rec = _profile_record("pmc_traffic.json", key)
         sq = _profile_record("pmc_valu.json", key)
         prov = _profile_provenance(rec, sq)
@@ -739,7 +806,16 @@ def main():
                                                     "SQ_INSTS_LDS_per_launch", "SQ_INSTS_VMEM_WR_per_launch"))
             rate = wi / (kern_ms_avg * 1e-3) / (4 * cus)            # VALU wave-instructions per second per SIMD
             waves_per_simd = sq.get("SQ_WAVES_per_launch", 4.0 * cus) / (4.0 * cus)
+            # the binding roof, stated as a time: every vector instruction of a wavefront occupies its SIMD's vector pipe
+            # for 4 cycles (16 lanes wide, 64 lanes per wavefront; fp64 and 32-bit alike on this chip) -- the launch cannot
+            # be shorter than instructions x 4 cycles / SIMDs at the clock the profiled launches ran at
+            clk = sq.get("clock_GHz_under_profiler")
+            pipe_ms = (wi * 4.0 / (4.0 * cus) / (clk * 1e9) * 1e3) if clk else None
             valu = {"valu_wave_instructions_per_sample": round(wi / units, 2),
+                    "pipe_bound_ms": round(pipe_ms, 4) if pipe_ms else None,
+                    "frac_of_pipe_bound": round(pipe_ms / kern_ms_avg, 4) if pipe_ms else None,
+                    "pipe_bound_how": "vector wave-instructions per launch (SQ_INSTS_VALU) x 4 cycles / (4 x %d SIMDs) / %.3f GHz (the clock of the "
+                                      "profiled launches); frac = that / this run's kernel_ms_avg" % (cus, clk or 0.0),
                     "all_wave_instructions_per_sample": round(all_wi / units, 2),
                     "waves_per_simd": round(waves_per_simd, 2),
                     "valu_issue_rate_per_simd_MHz": round(rate / 1e6, 1),
@@ -760,7 +836,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if args.arith == "f32" else "f64",
             "data": "synthetic",
             "config": {
                 "workload": label,
@@ -824,7 +900,7 @@ def main():
             tol_rows = {"f32": f32_rows}
             if other_rows is not None:
                 tol_rows["fma"] = other_rows
-            cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0)[0], n_samples,
+            cb = cpu_baseline(lambda n: configs.config_specs(args.config, n, lane0=0, out_noise_db=args.vowel_n)[0], n_samples,
                               args.cpu_seconds, first_rows, tol_rows)
             result["cpu_baseline"] = cb
             # the tolerance modes against the same CPU sample (first rows of their last launch)

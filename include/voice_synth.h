@@ -403,7 +403,10 @@ int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *
  *     failure behind that point aborts the communicators (ncclCommAbort) and leaves the node on the peer transport.
  * vs_node_link(): how shard's PCM reaches the root -- VS_NODE_LINK_SELF (same device, in place),
  * _PEER (peer DMA), _STAGED (no peer access between the two devices: the copies go through host
- * memory), _RCCL.  vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call. */
+ * memory), _RCCL.  vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call.
+ * vs_node_rccl_ranks(): ncclCommCount of the shard's communicator -- the number of ranks RCCL itself says it spans (the
+ * node's shard count on a healthy node), 0 while the node is on the peer transport, < 0 on error: what a pre-flight prints
+ * next to the PCI bus ids (cli/vs_bench.c --gpus N --rccl). */
 #define VS_NODE_TRANSPORT_PEER 0
 #define VS_NODE_TRANSPORT_RCCL 1
 #define VS_NODE_LINK_SELF 0
@@ -413,6 +416,7 @@ int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *
 int vs_node_set_transport(vs_node *node, int transport);
 int vs_node_link(const vs_node *node, int shard);
 int vs_node_last_rccl_error(const vs_node *node);
+int vs_node_rccl_ranks(vs_node *node, int shard);
 /* Synthesis with the final PCM gathered into the ROOT device's memory (root_dev: int16
  * [n_lanes][root_pitch] on devices[0]).  Every shard works through its block in chunks of 16384
  * utterances; with VS_NODE_OVERLAP a finished chunk travels to its rows of root_dev by a peer

@@ -154,7 +154,7 @@ def test_vs_bench_runs_from_plain_c():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["utterances_per_gpu"] == 3000 and d["value"] > 100
-    assert d["links"] == ["self", "self"]
+    assert d["links"] == ["self", "self"] and d["rccl_comm_ranks"] == [0, 0]   # (peer transport: no communicator)
     # the line says which devices took part (two logical shards = ONE device) and that the gathered PCM is what one
     # device gives alone, row for row
     assert len(d["devices"]) == 2 and d["devices"][0] == d["devices"][1] and d["distinct_devices"] == 1
@@ -165,6 +165,7 @@ def test_vs_bench_runs_from_plain_c():
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["value"] > 100 and d["links"] == ["self"]
+    assert d["rccl_comm_ranks"] == [1]                      # what RCCL itself says the communicator spans (ncclCommCount)
     assert d["gathered_equals_one_device"] is True and d["rows_verified_against_one_device"] == 3000
     # ... and logical shards of one device are refused, loudly
     r = subprocess.run([os.path.join(BIN, "vs_bench"), "--lanes", "3000", "--steps", "1", "--warmup", "0", "--gpus", "2", "--rccl"],

@@ -162,6 +162,64 @@ def test_a_phase_that_fails_on_one_rank_takes_all_ranks_out_together(tmp_path):
     assert r0["after"] == 3 and r1["after"] == 3
 
 
+def _worker_gather_with_a_failing_launch(rank, world, port, out_dir):
+    import json
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    phases = bench.Phases()
+    rec = {"rank": rank, "launched": []}
+    try:
+        n_lanes, n, chunk_rows = 17, 64, 2          # ragged shards of 6 / 6 / 5 rows: three rounds
+        pg = PipelinedGather(n_lanes, n, chunk_rows, "cpu")
+
+        def launch(k, tensor):
+            if rank == 1 and k == 1:
+                raise MemoryError("no room for chunk 1 on rank 1")     # mid-round: rank 1 has already sent chunk 0
+            tensor.fill_(100 * rank + k)
+            rec["launched"].append(k)
+
+        def gather():
+            pg.run(launch, progress=phases.tick)
+            return "gathered"
+
+        try:
+            bench.run_phase(phases, "timed gather", 60, gather, rank, "cpu")
+            rec["phase"] = "passed"
+        except bench.PhaseFailed as exc:
+            rec["phase"] = str(exc)
+        # nobody is stuck in a transfer: the next collective works on every rank
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        rec["after"] = int(t.item())
+        if rank == 0:
+            # what the healthy ranks sent did arrive (the caller discards the tensor all the same)
+            lo2, hi2 = shard_range(n_lanes, 2, world)
+            rec["rank2_rows"] = pg.full[lo2:hi2, 0].tolist()
+    finally:
+        json.dump(rec, open(os.path.join(out_dir, "g%d.json" % rank), "w"))
+        dist.destroy_process_group()
+
+
+def test_a_launch_that_fails_mid_gather_takes_all_ranks_out_together(tmp_path):
+    """PipelinedGather.run with a launch that raises on ONE rank in the middle of the rounds (three gloo ranks): the
+    failing rank keeps to the send schedule and raises behind the exchange, so the root's receives complete, nobody
+    hangs, and the phase agreement (bench.run_phase) ends the phase with PhaseFailed on every rank together"""
+    import json
+    mp.spawn(_worker_gather_with_a_failing_launch, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    r = [json.load(open(tmp_path / ("g%d.json" % k))) for k in range(3)]
+    assert "no room for chunk 1 on rank 1" in r[1]["phase"] and r[1]["launched"] == [0]      # it stopped launching ...
+    assert "another rank" in r[0]["phase"] and "another rank" in r[2]["phase"]               # ... and everybody knows
+    assert r[0]["launched"] == [0, 1, 2] and r[2]["launched"] == [0, 1, 2]
+    assert [x["after"] for x in r] == [6, 6, 6]
+    assert r[0]["rank2_rows"] == [200, 200, 201, 201, 202]
+
+
 def test_watchdog_stamps(tmp_path):
     """Phases: the watchdog sees a phase as stalled only once it has shown no progress for its allowance; tick() is
     progress; outside a phase nothing is ever stalled"""
@@ -202,3 +260,22 @@ def test_plain_bench_invocation_starts_its_own_ranks_and_propagates_their_exit_c
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, cwd=root, timeout=120,
                          env=dict(env, WORLD_SIZE="3", RANK="0"))
     assert out.returncode != 0 and b"WORLD_SIZE=3 but --gpus 2" in out.stderr
+
+
+def test_node_run_preflight_findings():
+    """bench.py --gpus N refuses to time a mis-bound launch (bench.preflight_errors; the N > 1 run that matters is the
+    driver's, unattended): N ranks on fewer than N devices, a rank that came up on another backend, a communicator that
+    does not span all ranks"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    def seen(n, pci=lambda r: "0000:%02x:00.0" % (5 + r), backend="nccl", size=None):
+        return [{"rank": r, "host": "box", "pci_bus_id": pci(r), "backend": backend, "comm_world_size": size or n} for r in range(n)]
+
+    assert bench.preflight_errors(seen(8), 8) == []
+    two_on_one = bench.preflight_errors(seen(8, pci=lambda r: "0000:%02x:00.0" % (5 + r // 2)), 8)
+    assert len(two_on_one) == 1 and "8 ranks drive 4 distinct devices" in two_on_one[0]
+    assert any("gloo" in w for w in bench.preflight_errors(seen(2, backend="gloo"), 2))
+    assert any("communicator sizes" in w for w in bench.preflight_errors(seen(4, size=2), 4))
+    assert any("ranks reported" in w for w in bench.preflight_errors(seen(3), 4))

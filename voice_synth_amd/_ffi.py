@@ -210,6 +210,7 @@ SYMBOLS = {
     "vs_node_set_transport": (C.c_int, [_vp, C.c_int]),
     "vs_node_link": (C.c_int, [_vp, C.c_int]),
     "vs_node_last_rccl_error": (C.c_int, [_vp]),
+    "vs_node_rccl_ranks": (C.c_int, [_vp, C.c_int]),
     "vs_node_synth_gather": (
         C.c_int,
         [_vp, _P(Lane), C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_int, _P(C.c_double), _P(C.c_double)],

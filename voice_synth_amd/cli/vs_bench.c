@@ -163,6 +163,10 @@ int main(int argc, char **argv)
       const int l = vs_node_link(node, d);
       snprintf(links + strlen(links), sizeof(links) - strlen(links), "%s\"%s\"", d ? ", " : "", (l >= 0 && l < 4) ? names[l] : "?");
     }
+    /* what RCCL itself says every shard's communicator spans (ncclCommCount): `gpus` on a healthy node */
+    char rccl_ranks[64 * 6 + 4] = "";
+    for (int d = 0; rc == VS_OK && d < gpus; d++)
+      snprintf(rccl_ranks + strlen(rccl_ranks), sizeof(rccl_ranks) - strlen(rccl_ranks), "%s%d", d ? ", " : "", vs_node_rccl_ranks(node, d));
     /* which device serves each shard: a node run must show that `gpus` DIFFERENT devices took part */
     char pcis[64 * 24 + 4] = "";
     char seen[64][32];
@@ -223,11 +227,11 @@ int main(int argc, char **argv)
       printf("{\"metric\": \"synthesised Msamples/s (whole node), PCM gathered into device %d\", \"value\": %.1f, "
              "\"unit\": \"Msamples/s\", \"n_gpus\": %d, \"ms_per_step\": %.4f, \"slowest_shard_compute_ms\": %.4f, "
              "\"steps\": %d, \"warmup\": %d, \"utterances_per_gpu\": %zu, \"samples_per_utterance\": %llu, "
-             "\"arith\": \"%s\", \"links\": [%s], \"devices\": [%s], \"distinct_devices\": %d, \"rows_verified_against_one_device\": %zu, "
+             "\"arith\": \"%s\", \"links\": [%s], \"rccl_comm_ranks\": [%s], \"devices\": [%s], \"distinct_devices\": %d, \"rows_verified_against_one_device\": %zu, "
              "\"gathered_equals_one_device\": %s, "
              "\"path\": \"vs_node_synth_gather, copies behind the synthesis (plans of every chunk included)\"}\n",
              devs[0], (double)n_lanes * (double)n_samples * steps / (sum_ms * 1e-3) / 1e6, gpus, sum_ms / steps, worst_shard,
-             steps, warmup, per_gpu, (unsigned long long)n_samples, arith, links, pcis, distinct, rows_verified,
+             steps, warmup, per_gpu, (unsigned long long)n_samples, arith, links, rccl_ranks, pcis, distinct, rows_verified,
              verify ? "true" : "null");
     if (out) vs_dev_free(root, out);
     vs_node_destroy(node);

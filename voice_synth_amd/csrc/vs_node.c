@@ -68,6 +68,7 @@ typedef struct VsRccl {
   int (*CommInitAll)(vs_nccl_comm *, int, const int *);
   int (*CommDestroy)(vs_nccl_comm);
   int (*CommAbort)(vs_nccl_comm);
+  int (*CommCount)(vs_nccl_comm, int *);
   int (*Send)(const void *, size_t, int, int, vs_nccl_comm, hipStream_t);
   int (*Recv)(void *, size_t, int, int, vs_nccl_comm, hipStream_t);
   int (*GroupStart)(void);
@@ -214,6 +215,7 @@ int vs_node_set_transport(vs_node *nd, int transport)
   *(void **)&R->CommInitAll = dlsym(R->lib, "ncclCommInitAll");
   *(void **)&R->CommDestroy = dlsym(R->lib, "ncclCommDestroy");
   *(void **)&R->CommAbort = dlsym(R->lib, "ncclCommAbort");
+  *(void **)&R->CommCount = dlsym(R->lib, "ncclCommCount"); /* (optional: the pre-flight's figure) */
   *(void **)&R->Send = dlsym(R->lib, "ncclSend");
   *(void **)&R->Recv = dlsym(R->lib, "ncclRecv");
   *(void **)&R->GroupStart = dlsym(R->lib, "ncclGroupStart");
@@ -253,6 +255,23 @@ int vs_node_link(const vs_node *nd, int shard)
 }
 
 int vs_node_last_rccl_error(const vs_node *nd) { return nd ? nd->last_rccl_error : 0; }
+
+int vs_node_rccl_ranks(vs_node *nd, int shard)
+{
+  if (!nd || shard < 0 || shard >= nd->n_shards) return VS_ERR_ARG;
+  if (nd->transport != VS_NODE_TRANSPORT_RCCL || shard >= nd->n_comm) return 0;
+  if (!nd->rccl.CommCount) return VS_ERR_UNSUPPORTED;
+  vs_nccl_comm c = vs_commguard_enter(&nd->guard[shard]);
+  if (!c) return 0;
+  int count = 0;
+  const int e = nd->rccl.CommCount(c, &count);
+  vs_commguard_leave(&nd->guard[shard]);
+  if (e != 0) {
+    nd->last_rccl_error = e;
+    return VS_ERR_HIP;
+  }
+  return count;
+}
 
 void vs_node_destroy(vs_node *nd)
 {

@@ -86,7 +86,15 @@ class PipelinedGather:
     def run(self, launch, progress=None):
         """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done.
         progress (optional) is called once per round of chunks handed to the transport and once per completed
-        transfer: a watchdog's sign of life (bench.py)."""
+        transfer: a watchdog's sign of life (bench.py).
+
+        A launch that RAISES on one rank (no room for a plan, a refused kernel) must not leave the others waiting for
+        transfers that never come -- an unmatched send or receive never completes.  The failing rank therefore stops
+        launching but keeps to the schedule: it hands over the rest of its chunks as they are (their rows are then
+        whatever the buffer held: the caller must not use the gathered tensor), waits for the exchange like everybody
+        else, and raises the launch's exception only THEN.  Every rank so leaves run() in step, and the agreement that
+        ends the caller's phase (bench.py run_phase: an all-reduce of an ok flag) takes them out together."""
+        failed = None
         work = []
         peers = [r for r in range(self.world) if r != self.dst]
         peer_edges = {}
@@ -97,7 +105,11 @@ class PipelinedGather:
         for k in range(n_rounds):
             ev = None
             if k < len(self.chunks):
-                launch(k, self.chunks[k])
+                if failed is None:
+                    try:
+                        launch(k, self.chunks[k])
+                    except Exception as exc:  # noqa: BLE001 - re-raised behind the exchange
+                        failed = exc
                 if self.cuda:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream())
@@ -133,4 +145,6 @@ class PipelinedGather:
         if self.cuda:
             self.comm_stream.synchronize()
             torch.cuda.current_stream().synchronize()
+        if failed is not None:
+            raise failed
         return self.full
