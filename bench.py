@@ -351,7 +351,7 @@ def fresh_batches(eng, dev, stream, lanes, n_samples, out, pitch, per_gpu, batch
 def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, warm=5, out_noise_db=None):
     """One BASELINE configuration outside the timed region: plan, `warm` untimed launches (the chip has idled through the
     plan's host work and comes back on a low clock), then HIP events on the launch stream around each of `launches`
-    launches, in both arithmetic contracts.  Returns one record per contract:
+    launches, in the three arithmetics (exact, then the opt-in fma and f32).  Returns one record per arithmetic:
     {workload, kernel, arith, kernel_ms_avg, kernel_ms_min, roofline_frac, ...}.
     out_noise_db: the same utterances with "vowel -n <dB>" as well (vowel_new.c:302-324): a launch is then
     the fused kernel (its filter wavefronts take the frame powers along), a scan and the streaming noise pass; the events
@@ -370,8 +370,8 @@ def measure_config(eng, dev, stream, cfg_i, n_lanes, arith_first, launches=10, w
     out = torch.empty((n_lanes, pitch), dtype=torch.int16, device=dev)
     recs = []
     try:
-        other = vs.VS_ARITH_FMA if arith_first == vs.VS_ARITH_EXACT else vs.VS_ARITH_EXACT
-        for ar in (arith_first, other):
+        order = [arith_first] + [a_ for a_ in (vs.VS_ARITH_EXACT, vs.VS_ARITH_FMA, vs.VS_ARITH_F32) if a_ != arith_first]
+        for ar in order:
             eng.set_arith(ar)
             for _ in range(warm):
                 plan.launch(vs.VS_KIND_SYNTH, out.data_ptr(), out_pitch=pitch)

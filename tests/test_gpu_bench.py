@@ -195,18 +195,17 @@ def test_bench_line_carries_every_baseline_configuration():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _check(out.stdout.decode().strip().splitlines()[-1], 3)
     oc = d["other_configs"]
-    assert [(r["baseline_config_index"], r["arith"]) for r in oc] == [(1, "exact"), (1, "fma"), (3, "exact"), (3, "fma"), (4, "exact"), (4, "fma"),
-                                                                      (2, "exact"), (2, "fma")]
-    # the last two: config 3 with "vowel -n 20" on every utterance -- the fused kernel that takes the frame powers along,
+    assert [(r["baseline_config_index"], r["arith"]) for r in oc] == [(c, a) for c in (1, 3, 4, 2) for a in ("exact", "fma", "f32")]
+    # the last three: config 3 with "vowel -n 20" on every utterance -- the fused kernel that takes the frame powers along,
     # the scan, the streaming noise pass: one launch of the plan, bracketed as a whole
-    for r in oc[6:]:
+    for r in oc[9:]:
         assert r["vowel_n_db"] == 20 and r["bytes_per_sample"] == 6
         assert r["kernel"].startswith("vs_synth_ws_pow_kernel<") and r["kernel"].endswith("+ vs_out_power_fill_kernel + vs_out_noise_kernel")
         assert r["kernel_ms_avg"] > d["roofline"]["kernel_ms_min"]
     for r in oc:
         assert "error" not in r and r["kernel"].startswith("vs_synth") and r["kernel_ms_avg"] >= r["kernel_ms_min"] > 0
         assert abs(r["roofline_frac"] - 2 * r["utterances"] * r["samples_per_utterance"] / (r["kernel_ms_avg"] * 1e-3) / 8e12) < 2e-4
-    assert oc[2]["utterances"] == 32768 and oc[2]["samples_per_utterance"] == 44100
+    assert oc[3]["utterances"] == 32768 and oc[3]["samples_per_utterance"] == 44100
     # ... and what a caller pays who makes a plan per batch of new utterances (plan k + 1 overlapped with kernel k)
     fb = d["fresh_batches"]
     assert "error" not in fb and fb["batches"] >= 10 and fb["utterances_per_batch"] == 65536

@@ -387,17 +387,19 @@ __device__ __forceinline__ void vs_superstep_f32(VsF32Filter &f, const int16_t *
        * half of yp[m+1].  The two chains are written side by side: a packed multiply-add that reads the result of the one
        * in front of it costs a wait state (an s_nop: an issue slot), and all of the odd sample but its newest tap is
        * independent of the even one */
-      vs_f32x2 pe = {(float)xin[2 * m] * f.gain, 0.0f};
-      vs_f32x2 po = {(float)xin[2 * m + 1] * f.gain, 0.0f};
+      /* (the input term x*gain joins at the END of each chain, as one fused multiply-add into the sum of the two halves:
+       * the chains start from a packed product instead of {x*gain, 0} -- a multiplication and a zero less per sample) */
+      vs_f32x2 pe = f.nce[0] * f.yp[(m + 11) % 12];
+      vs_f32x2 po = f.nco[0] * f.yp[(m + 11) % 12];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) {
+      for (int k = 1; k < 10; ++k) {
         pe = __builtin_elementwise_fma(f.nce[k], f.yp[(m + 11 - k) % 12], pe);
         po = __builtin_elementwise_fma(f.nco[k], f.yp[(m + 11 - k) % 12], po);
       }
       pe = __builtin_elementwise_fma(f.nce[10], f.yp[(m + 1) % 12], pe);
       float sc = __builtin_fmaf(f.na22, f.yp[(m + 1) % 12].y, po.y);
-      const float acc0 = pe.x + pe.y;
-      sc = sc + po.x;
+      const float acc0 = __builtin_fmaf((float)xin[2 * m], f.gain, pe.x + pe.y);
+      sc = __builtin_fmaf((float)xin[2 * m + 1], f.gain, sc + po.x);
       const float y1 = f.yp[(m + 11) % 12].y;
       o0 = vs_round_f32(PRE1 ? (acc0 - y1) : __builtin_fmaf(-f.pre, y1, acc0)); /* vowel_new.c:284 */
       const float acc1 = __builtin_fmaf(f.na1, acc0, sc);

@@ -21,6 +21,16 @@
 __device__ __forceinline__ void vs_cycle_scalars(const VsCfg &c, VsGen &s, VsDiag &dg)
 {
   VS_DIAG_ADD(dg, 7)
+#if defined(VS_TIMING_STUB) && (VS_TIMING_STUB & 1)
+  /* measurement builds only (tools/insts.sh): what the per-cycle draws and recursions cost in instructions -- wrong samples */
+  s.T = c.P;
+  s.d += 3u;
+  s.K_next = c.K;
+  s.amp_next = (float)c.amp;
+  s.S_next = 0.0f;
+  s.pend = true;
+  return;
+#endif
   VsBlk blk;
   blk.idx = 0xFFFFFFFFu; blk.b0 = blk.b1 = blk.b2 = blk.b3 = 0u;
   /* ---- jitter: fg:248-291 ---- */
@@ -501,7 +511,11 @@ __device__ __forceinline__ void vs_cycle_emit(const VsCfg &c, VsGen &s, int16_t 
     x_pow = psum / ((float)T3 - (float)T4);
     const float aux = (float)(1.0 + (double)(((float)T3 - (float)T4) / ((float)T)));
     const float arg = 12.0f * aux * x_pow / c.noise;
+#if defined(VS_TIMING_STUB) && (VS_TIMING_STUB & 2)
+    const int NDW = 2000 + (int)(arg * 0.0f); /* measurement builds only: what the noise width costs */
+#else
     const int NDW = vs_isqrt_floor((double)arg);
+#endif
     const double NDWd = (double)NDW;
     const double half = NDWd / 2.0;
     const int ntail = (T > T3) ? (T - T3) : 0;
