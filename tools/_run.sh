@@ -1,5 +1,4 @@
 set -o pipefail
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout -k 10 200 python tools/diag_ws.py 3 > gpurun_out/diag3.txt 2>&1 || { tail -5 gpurun_out/diag3.txt; exit 1; }
-timeout -k 10 200 python tools/diag_ws.py 5 > gpurun_out/diag5.txt 2>&1 || { tail -5 gpurun_out/diag5.txt; exit 1; }
-cat gpurun_out/diag3.txt; cat gpurun_out/diag5.txt
+tools/insts.sh 3 65536 16000 pairok | grep -E "^==|ws_kernel|kernel<0, 1|synth:"
+VS_LIB=libvoicesynth_pairok.so timeout -k 10 300 python -m pytest tests/test_gpu_golden.py -m gpu -x -q 2>&1 | tail -2
