@@ -15,6 +15,7 @@
 #   tools/gpu.sh diag                           phase breakdown from the diagnostic build
 #   tools/gpu.sh full <tag>                     the round's evidence pass (copy the summaries into profiles/)
 #   tools/gpu.sh configs <tag>                  bench.py --config 2 / 4 / 5 under rocprofv3 --kernel-trace --stats
+#   tools/gpu.sh pmcset 3|3n|2|4|5              traffic + SQ counter passes of one configuration's keys (exact, fma[, f32])
 # Steps may be chained:  tools/gpu.sh test -- ab default r2 -- bench
 # Boxes differ by up to 10 % in sustained clock, so variants are only ever compared within one call.
 set -o pipefail
@@ -102,6 +103,32 @@ run_step() {
       run_step sq config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
       run_step bench || return 1
       cp gpurun_out/bench.json gpurun_out/${tag}_bench_n1.json ;;
+    pmcset)
+      # traffic + SQ passes for a set of keys on the tree as it stands -> profiles/pmc_{traffic,valu}.json (copy them back from gpurun_out/):
+      #   tools/gpu.sh pmcset 3        config 3 in the three arithmetics + config 3 with vowel -n (fused kernel and noise pass)
+      #   tools/gpu.sh pmcset 2 | 4 | 5     that configuration, exact and fma
+      local which=${1:-3}
+      if [ "$which" = 3 ]; then
+        run_step traffic config3_exact_65536 "vs_synth_ws_kernel<0" || return 1
+        run_step sq config3_exact_65536 "vs_synth_ws_kernel<0" || return 1
+        run_step traffic config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
+        run_step sq config3_fma_65536 "vs_synth_ws_kernel<1" --arith fma || return 1
+        run_step traffic config3_f32_65536 "vs_synth_ws_kernel<2" --arith f32 || return 1
+        run_step sq config3_f32_65536 "vs_synth_ws_kernel<2" --arith f32 || return 1
+      elif [ "$which" = 3n ]; then
+        run_step traffic config3_onoise_exact_65536 "vs_synth_ws_pow_kernel<0" --vowel-n 20 || return 1
+        run_step sq config3_onoise_exact_65536 "vs_synth_ws_pow_kernel<0" --vowel-n 20 || return 1
+        run_step traffic config3_onoise_noisepass_exact_65536 "vs_out_noise_kernel" --vowel-n 20 || return 1
+        run_step sq config3_onoise_noisepass_exact_65536 "vs_out_noise_kernel" --vowel-n 20 || return 1
+      else
+        local key=config${which}; [ "$which" = 4 ] && key=config4_shard
+        local lanes=65536; [ "$which" = 4 ] && lanes=32768; [ "$which" = 2 ] && lanes=1024
+        local roles=3; [ "$which" = 2 ] && roles=2
+        run_step traffic ${key}_exact_$lanes "vs_synth_ws_kernel<0, true, $roles" --config $which || return 1
+        run_step sq ${key}_exact_$lanes "vs_synth_ws_kernel<0, true, $roles" --config $which || return 1
+        run_step traffic ${key}_fma_$lanes "vs_synth_ws_kernel<1, true, $roles" --config $which --arith fma || return 1
+        run_step sq ${key}_fma_$lanes "vs_synth_ws_kernel<1, true, $roles" --config $which --arith fma || return 1
+      fi ;;
     configs)
       # the other BASELINE configurations under rocprofv3 --kernel-trace --stats:  tools/gpu.sh configs <tag>
       local tag=${1:-r04}
