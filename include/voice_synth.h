@@ -124,7 +124,8 @@ typedef struct vs_cycle_rec {
 /* VS_ARITH_F32:   the recurrence in single precision, two taps per packed multiply-add -- 1.25 x the speed of VS_ARITH_FMA
  *                 for a MEASURED distance from the reference (single precision is marginal against 1e-5):
  *                 per table at gain 10 / pre-emphasis 1, RMS of full scale 4.6e-6 (table 7) .. 1.9e-5 (/i/), above 1e-5
- *                 for /i/, /u/ and table 1; at most 7 LSB there, 28 LSB for table 5 without pre-emphasis.  The whole table
+ *                 for /i/, /u/ and table 1; at most 6 LSB there, 25 LSB for table 5 without pre-emphasis; 7.5e-6 over
+ *                 BASELINE config 3's mix of tables.  The whole table
  *                 is tests/golden/f32_bounds.json (made by tools/f32_survey.py on the device); tests/test_gpu_f32.py holds
  *                 the kernels to it.  Only the fused wave-specialised kernels have this arithmetic: source-only and
  *                 filter-only launches, the one-wave kernel and coefficient sets of 23..40 taps run VS_ARITH_FMA. */

@@ -323,7 +323,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
 /*
  * VS_ARITH_F32 (opt-in): the recurrence of vowel_new.c:279-281 in SINGLE precision with PACKED fused
  * multiply-adds -- two taps per V_PK_FMA_F32 -- for callers who accept a measured distance from the reference instead of
- * its rounding sequence (include/voice_synth.h has the table: RMS up to 1.9e-5 of full scale, 28 LSB at most, worst for
+ * its rounding sequence (include/voice_synth.h has the table: RMS up to 1.9e-5 of full scale, 25 LSB at most, worst for
  * /i/ at the default gain; tests/test_gpu_f32.py holds the kernels to it).  The window is 12 register pairs
  * {y[2q], y[2q+1]} (24 registers where the double window takes 48); for an even sample index the 22 taps are 11 aligned
  * pairs, for an odd one 10 pairs plus the newest and the oldest tap on their own: nce[k] = -{A[2k+2], A[2k+1]},
