@@ -221,4 +221,9 @@ def test_full_grid_of_random_utterances_over_mixed_rings():
     k, bad, st, name, info = fuzz_fullgrid.run(4242, 42000, 3000)
     print("%d lanes, %s, %s" % (k, name, info))
     assert k > 33000 and st == 0 and bad == 0
-    assert name.startswith("vs_synth_ws_kernel") and info["lds_bytes"] > 64 * 1024     # mixed rings: several rings per workgroup
+    # a third of the utterances ask for vowel -n: the fused kernel takes the frame powers along (pre-emphasis differs per
+    # utterance: the general instantiation), a scan and the noise pass follow
+    assert name.startswith("vs_synth_ws_pow_kernel<0, false, 3> + vs_out_power_fill_kernel") and info["lds_bytes"] > 64 * 1024  # mixed rings
+    # ... and the same utterances without output noise: the plain kernel
+    k, bad, st, name, info = fuzz_fullgrid.run(4242, 42000, 3000, onoise=False)
+    assert k > 33000 and st == 0 and bad == 0 and name == "vs_synth_ws_kernel<0, false, 3>"

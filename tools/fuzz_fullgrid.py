@@ -20,16 +20,19 @@ from oracle import pyoracle as po  # noqa: E402
 from test_gpu_properties import _fuzz_lanes  # noqa: E402
 
 
-def lanes_for(seed, count, noisy_share=0.85, one_cq=True):
-    """the suite's random utterances without `vowel -n` (its power sums take the one-wave kernel), most of them with
-    glottal noise (three roles want a noisy majority), one sample rate per batch (a plan has one length).  one_cq: every
+def lanes_for(seed, count, noisy_share=0.85, one_cq=True, onoise=True):
+    """the suite's random utterances, most of them with glottal noise (three roles want a noisy majority), one sample rate
+    per batch (a plan has one length -- and, since round 6, one frame length: the third of the utterances that ask for
+    `vowel -n` get their frame powers from the filter wavefronts of the fused kernel, vs_synth_ws_pow_kernel; onoise=False
+    drops the output noise as rounds 4 and 5 did, when it sent the whole plan to the one-wave kernel).  one_cq: every
     utterance keeps the default closed quotient, so that a group of 64 neighbouring periods needs a handful of cos rows
     and the mixed rings fit; with random quotients a group stages up to 64 rows and the plan stays on uniform rings"""
     rng = np.random.default_rng(seed + 77)
     base = _fuzz_lanes(seed, count)
     fs = int(rng.choice([16000, 22050, 11025]))
     for lane in base:
-        lane.out_snr = 0.0
+        if not onoise:
+            lane.out_snr = 0.0
         lane.fs = fs
         if one_cq:
             lane.cq = 0.55
@@ -44,8 +47,8 @@ def lanes_for(seed, count, noisy_share=0.85, one_cq=True):
     return ok
 
 
-def run(seed, count, n, one_cq=True):
-    lanes = lanes_for(seed, count, one_cq=one_cq)
+def run(seed, count, n, one_cq=True, onoise=True):
+    lanes = lanes_for(seed, count, one_cq=one_cq, onoise=onoise)
     arr = (vs.Lane * len(lanes))(*lanes)
     eng = vs.Engine(0)
     try:
