@@ -35,8 +35,11 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
 /*
  * vowel -n inside the fused kernels (vowel_new.c:303-309): the filter wavefront of a wave-specialised kernel whose lanes
  * share one position and one frame length sums (float)y*y as its results are packed -- in sample order, so the float
- * rounding sequence is the reference's -- and at a frame's last sample (frames end on multiples of 4 samples: Lframe is
- * a multiple of 100, a super-step starts on a multiple of 24) turns the sum into that frame's NoiseDistWidth.  Three
+ * rounding sequence is the reference's.  Frames end on multiples of 4 samples (Lframe is a multiple of 100, a super-step
+ * starts on a multiple of 24): behind every fourth sample the sum is set aside and started afresh IF the frame ends there --
+ * a scalar compare and two selects, no branch inside the super-step (a branch there makes the old and the new register
+ * assignment of everything that is live meet behind it: the first version cost 2.9 vector instructions per sample in
+ * copies) -- and the caller turns what was set aside into that frame's NoiseDistWidth between two super-steps.  Three
  * vector instructions per sample in place of a 2 B/sample streaming pass over the finished PCM.  What it cannot vouch for
  * it leaves to that pass (vs_out_power_kernel, fill mode): a frame during which round2int()'s quirk path rounded a
  * super-step again gets NaN, and frames behind the last whole super-step are not counted in done[].
@@ -44,6 +47,7 @@ __device__ __forceinline__ void vs_unpack8(const vs_u32x4 v, int *x)
 #define VS_ONDW_UNKNOWN 0x7FC00000u /* NaN: "this frame's power is the streaming pass's to find" */
 struct VsFramePower {
   float sum;   /* aux of vowel_new.c:303-306 for the frame this lane is in */
+  float done;  /* ... of the frame that ended inside the super-step just run (tb != 0) */
   int tb;      /* wave-uniform: the frame ends behind sample tb - 1 of the super-step being run (4, 8, .. 24), 0: not in it */
   int len;     /* wave-uniform: samples of the frame that ends there (ni of vw:307) */
   int frame;   /* wave-uniform: index of the frame the super-step starts in */
@@ -85,7 +89,7 @@ __device__ __forceinline__ void vs_power_pair(uint32_t w, float &aux)
   aux += lo * lo;
   aux += hi * hi;
 }
-/* the frame's entry of the table: its width from the sum, or "unknown" */
+/* the entry of the frame that has just ended: its width from the sum that was set aside, or "unknown" */
 __device__ __forceinline__ void vs_frame_power_store(const VsFramePower &fp, bool unknown)
 {
   const long gl = fp.first_lane + (long)(threadIdx.x & (VS_WAVE - 1));
@@ -93,13 +97,16 @@ __device__ __forceinline__ void vs_frame_power_store(const VsFramePower &fp, boo
     const VsDevLane *__restrict__ L = fp.lanes + gl;
     const float snr = L->out_snr;
     if (snr > 0.0f)
-      fp.ondw[(long)L->row * fp.ondw_pitch + fp.frame] = unknown ? __uint_as_float(VS_ONDW_UNKNOWN) : vs_noise_width(fp.sum, fp.len, snr);
+      fp.ondw[(long)L->row * fp.ondw_pitch + fp.frame] = unknown ? __uint_as_float(VS_ONDW_UNKNOWN) : vs_noise_width(fp.done, fp.len, snr);
   }
 }
-__device__ __forceinline__ void vs_frame_power_flush(VsFramePower &fp)
+/* behind sample t of a super-step (t + 1 a multiple of 4): if the frame ends here, its sum is set aside and the next one's
+ * starts -- tb is wave-uniform, so `ends` is a scalar condition and the two selects take it as a mask */
+__device__ __forceinline__ void vs_frame_power_mark(VsFramePower &fp, int t)
 {
-  vs_frame_power_store(fp, fp.bad);
-  fp.sum = 0.0f;
+  const bool ends = fp.tb == t + 1;
+  fp.done = ends ? fp.sum : fp.done;
+  fp.sum = ends ? 0.0f : fp.sum;
 }
 
 /*
@@ -283,7 +290,7 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       if (EAGER && (t & 1)) pk[(t >> 1) % PKN] = vs_clamp_pack16(outv[t - 1], outv[t]);
       if (POW && (t & 1)) {
         vs_power_pair(pk[(t >> 1) % PKN], fp->sum);
-        if ((t & 3) == 3 && fp->tb == t + 1) vs_frame_power_flush(*fp); /* (wave-uniform) */
+        if ((t & 3) == 3) vs_frame_power_mark(*fp, t);
       }
       if ((t & 7) == 7) put8(t >> 3);
       /* keep each sample's products next to its chain: hoisted across samples they only park
@@ -295,12 +302,9 @@ __device__ __forceinline__ void vs_superstep(const double (&a)[VS_ORDER + 1], do
       /* some argument of this super-step may sit in round2int()'s quirk set (a signal that has
        * decayed to below 2^-54, or one chance in 2^32 per sample): round all of it again,
        * literally, and store it again */
-      if (POW) {
-        /* the sums have seen the first rounding: the frame this super-step ends in, and the one that ended inside it
-         * (its width is in the table already), are left to the streaming pass */
-        if (fp->tb) vs_frame_power_store(*fp, true);
-        fp->requirk = true;
-      }
+      /* the sums have seen the first rounding: the frame this super-step ends in, and the one that ended inside it, are
+       * left to the streaming pass (the caller stores "unknown") */
+      if (POW) fp->requirk = true;
 #pragma unroll
       for (int t = 0; t < VS_SS; ++t) {
         const double y1 = (t == 0) ? ym1 : y[t - 1];
@@ -411,7 +415,7 @@ __device__ __forceinline__ void vs_superstep_f32(VsF32Filter &f, const int16_t *
       pk[m & 3] = vs_clamp_pack16(o0, o1);
       if (POW) {
         vs_power_pair(pk[m & 3], fp->sum);
-        if ((m & 1) && fp->tb == 2 * m + 2) vs_frame_power_flush(*fp); /* (wave-uniform) */
+        if (m & 1) vs_frame_power_mark(*fp, 2 * m + 1);
       }
       if ((m & 3) == 3) {
         vs_u32x4 v;

@@ -548,7 +548,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
     VsFramePower fp;
     int f_len = 0, f_left = 0; /* length of the frame the next super-step starts in; what is left of it */
     if (POW) {
-      fp.sum = 0.0f;
+      fp.sum = fp.done = 0.0f;
       fp.frame = 0;
       fp.bad = fp.requirk = false;
       fp.lanes = args.lanes;
@@ -576,6 +576,7 @@ __device__ __forceinline__ void vs_filter_wave(const VsKernelArgs &args, const V
                                                                          N, true, outv, xpre, true, &fp);
       if (POW) {
         if (fp.tb) { /* a frame ended behind sample tb - 1; the rest of the super-step went to the next one's sum */
+          vs_frame_power_store(fp, fp.bad || fp.requirk);
           fp.frame += 1;
           fp.bad = fp.requirk;
           const int rest = N - (n + fp.tb);
