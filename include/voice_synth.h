@@ -288,6 +288,10 @@ int vs_ctx_device_pci(const vs_ctx *ctx, char *bus_id, size_t len);
  * under it, a context does not survive fork(). */
 int vs_plan_create(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples,
                    vs_plan **plan);
+/* May be called while launches of the plan are still running: the plan's device blocks (records, tables, the output-noise
+ * tables) are not freed -- hipFree waits for the whole device, i.e. for the kernels of the batches behind -- but kept by the
+ * context (up to 32 of them: 9 MB per plan of 65536 utterances) and handed to the next plan of that size once the launches
+ * that read them are over (an event recorded behind the plan's last launch).  vs_ctx_trim() / vs_ctx_destroy() free them. */
 void vs_plan_destroy(vs_plan *plan);
 
 /* Launch on the context's stream; returns without waiting for the device.
@@ -365,7 +369,8 @@ int vs_synth_rows(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_sa
 /* Pinned host memory for callers without a HIP binding of their own. */
 int vs_host_alloc(vs_ctx *ctx, size_t bytes, void **ptr);
 int vs_host_free(vs_ctx *ctx, void *ptr);
-/* Releases the buffers the context keeps between calls (device PCM chunks, staging, streams). */
+/* Releases the buffers the context keeps between calls (device PCM chunks, staging, streams, the device blocks of
+ * destroyed plans). */
 int vs_ctx_trim(vs_ctx *ctx);
 /* fg:246-423; flow is int16 [n_lanes][n_samples].  recs/ncyc optional (NULL). */
 int vs_source(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_t n_samples, int16_t *flow,

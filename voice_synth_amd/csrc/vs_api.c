@@ -948,7 +948,11 @@ static int plan_mark_launch(vs_plan *p)
 {
   vs_ctx *ctx = p->ctx;
   if (!p->last_launch) VS_HIP(ctx, hipEventCreateWithFlags(&p->last_launch, hipEventDisableTiming));
+  /* a caller who moved the context to another stream between two launches of this plan: the new stream waits for the old
+   * launches first, so that the event recorded on it still stands behind EVERY launch that reads the plan's blocks */
+  else if (p->last_stream != ctx->stream) VS_HIP(ctx, hipStreamWaitEvent(ctx->stream, p->last_launch, 0));
   VS_HIP(ctx, hipEventRecord(p->last_launch, ctx->stream));
+  p->last_stream = ctx->stream;
   return VS_OK;
 }
 

@@ -97,6 +97,7 @@ struct vs_plan {
   size_t n_lanes, n_samples;
   VsDevLane *d_lanes;
   hipEvent_t last_launch;   /* recorded behind every launch (and reseed) of this plan; NULL until the first: what its blocks retire behind */
+  hipStream_t last_stream;  /* ... and the stream it was last recorded on */
   size_t cap_lanes, cap_small, cap_sink, cap_ondw, cap_odone; /* what the blocks below really hold (they may come from the context's cache of retired blocks) */
   char *d_small;     /* plans that copy: ONE device block for cos rows + taps, the mixed-rings table and the error word (d_costab, d_group_map, d_err point into it) */
   double *d_costab;
