@@ -47,8 +47,8 @@ def test_f32_mode_stays_within_its_measured_bounds(f32_engine):
 
 
 def test_f32_mode_on_the_baseline_shapes(f32_engine):
-    """one launch of config 3 (three roles, full grid), config 4's shard (three roles, spread layout), config 2's shape (two
-    roles) and config 5 (mixed rings), 4096..65536 utterances: the single-precision kernels are the ones that run, the
+    """one launch of config 3 (three roles, full grid), config 4's shard (three roles, spread layout), config 2's shape (no
+    glottal noise) and config 5 (mixed rings), 4096..65536 utterances: the single-precision kernels are the ones that run, the
     output stays within 32 LSB of the exact oracle everywhere and within 4e-5 RMS"""
     for index, n, check in ((3, 65536, 2048), (4, 32768, 1024), (2, 1024, 1024), (5, 65536, 2048)):
         specs, fs, dur, label = configs.config_specs(index, n)

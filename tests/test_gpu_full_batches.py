@@ -81,7 +81,7 @@ def test_one_launch_of_the_whole_batch_every_sample(engine, index, n, kernel, mi
     assert bad == 0
 
 
-@pytest.mark.parametrize("index,n,roles", [(3, 65536, 3), (5, 65536 - 219, 3), (4, 32768, 3), (2, 1024, 2)])
+@pytest.mark.parametrize("index,n,roles", [(3, 65536, 3), (5, 65536 - 219, 3), (4, 32768, 3), (2, 1024, 3)])
 def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
     """vowel -n (vowel_new.c:302-324) behind the kernels bench.py times: the plan of a batch in which every utterance asks
     for output noise still takes the wave-specialised kernel of its shape -- its filter wavefronts take the frame powers
@@ -89,7 +89,7 @@ def test_one_launch_with_output_noise_every_sample(engine, index, n, roles):
     (vs_out_power_fill_kernel), the noise is one streaming pass over the finished PCM (vs_out_noise_kernel) -- and every
     sample equals the oracle's: config 3 (16 kHz: frames of 800 samples), config 5's F0 sweep over mixed
     rings with a ragged last group, config 4's shard (22.05 kHz, 2 s: frames of 1100 samples, rows that are no multiple of
-    8 samples long, a last frame of 100) and config 2's shape (no glottal noise: two roles)"""
+    8 samples long, a last frame of 100) and config 2's shape (no glottal noise)"""
     specs, fs, dur, label = configs.config_specs(index, n, out_noise_db=20)
     lanes, d = vs.lanes_from_specs(specs)
     ns = vs.num_samples(fs, d)

@@ -138,12 +138,12 @@ def test_longest_period_of_the_wide_ring_and_beyond(engine):
 
 def test_which_fused_kernel_a_plan_takes(engine):
     """the roles of the wave-specialised kernel are chosen by the shape of the work, not by what happens to
-    fit the LDS: three (open phase | noise | filter) on a full grid of deep rings with glottal noise
-    (BASELINE config 3; config 5's F0 sweep too, once every group has the ring depth ITS periods need -- mixed rings),
-    two where the rings hold barely a cycle (the F0 sweep over uniform rings: a filter wavefront
-    that waits for all of its lanes starves there), where there is no glottal noise (config 2's shape),
-    and three again on half-filled chips with glottal noise (config 4's shard: the filter wavefront alone on its
-    SIMD, open phase and noise together on the next; a 16384-utterance chunk: a SIMD per wavefront)."""
+    fit the LDS: three (open phase | noise | filter) wherever the rings are deep -- a full grid (BASELINE config 3; config
+    5's F0 sweep too, once every group has the ring depth ITS periods need: mixed rings), half-filled chips (config 4's
+    shard: the filter wavefront alone on its SIMD, open phase and noise together on the next; a 16384-utterance chunk: a SIMD
+    per wavefront), with glottal noise or without (config 2's shape: since round 6, profiles/r06_roles_without_noise.txt) --
+    and two where the rings hold barely a cycle (the F0 sweep over uniform rings: a filter wavefront that waits for all of
+    its lanes starves there)."""
     def kernel(cfg, n):
         specs, fs, dur, _ = configs.config_specs(cfg, n)
         lanes, d = vs.lanes_from_specs(specs)
@@ -158,10 +158,10 @@ def test_which_fused_kernel_a_plan_takes(engine):
         assert kernel(5, 65536) == "vs_synth_ws_kernel<0, true, 2>"
     finally:
         engine.set_tuning()
-    assert kernel(2, 65536) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(2, 65536) == "vs_synth_ws_kernel<0, true, 3>"
     assert kernel(4, 32768) == "vs_synth_ws_kernel<0, true, 3>"
     assert kernel(3, 16384) == "vs_synth_ws_kernel<0, true, 3>"   # a chunk of the delivery pipelines
-    assert kernel(2, 1024) == "vs_synth_ws_kernel<0, true, 2>"
+    assert kernel(2, 1024) == "vs_synth_ws_kernel<0, true, 3>"
     # ... over rings of 2.4 of the longest cycle where at most two groups share a CU, 1.7 (capped by the LDS) on full grids
     def slots(cfg, n):
         specs, fs, dur, _ = configs.config_specs(cfg, n)

@@ -694,13 +694,15 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * -- open phase | noise | filter -- if the extra progress words and order boxes still fit next
        * to four rings.  Otherwise two: generator | filter. */
       const int bytes3 = (int)((lds_bytes + VS_SYNC_WORDS_3 * VS_WAVE * sizeof(int) + 15) & ~(size_t)15);
-      const size_t noisy = st.n_noisy;
-      /* only where there is noise to hand over: without it the third wavefront just relays
-       * progress words (BASELINE config 2's shape: 3.01 ms against 2.75 with two roles); and only over
-       * deep rings: the filter wavefront of the three-role kernel waits for ALL of its lanes, which a
-       * ring of barely one cycle cannot feed (BASELINE config 5's F0 sweep: 4.4 ms against 3.66 with two
-       * roles, profiles/r03_kernel_experiments.txt) */
-      if (wave_specialised && ws_pairs == 4 && 2 * noisy >= n_lanes && all_deep && (gmap || (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT))
+      /* only over deep rings: the filter wavefront of the three-role kernel waits for ALL of its lanes, which a
+       * ring of barely one cycle cannot feed (BASELINE config 5's F0 sweep over uniform rings: 4.4 ms against 3.66 with
+       * two roles, profiles/r03_kernel_experiments.txt).  With or without glottal noise: until round 5 batches without it
+       * (BASELINE config 2's shape) took two roles -- the third wavefront only relays progress words there, and round 3
+       * measured 3.01 ms against 2.75 on the full grid -- but with the kernels as they are now three roles win on every
+       * shape measured (round 6, profiles/r06_roles_without_noise.txt: config 2 at 1024 utterances 1.56 against 1.59 ms
+       * exact, 0.99 against 1.13 fma, 0.84 against 0.92 f32; at 65536 2.57 / 2.68 exact; an F0 sweep without noise 2.99 /
+       * 3.02): the open-phase wavefront hands the bookkeeping of finished cycles to a wavefront that has nothing else to do */
+      if (wave_specialised && ws_pairs == 4 && all_deep && (gmap || (size_t)4 * (size_t)bytes3 <= VS_LDS_LIMIT))
         ws_roles = 3;
       /* Half-filled chips (one or two groups per workgroup: BASELINE config 4's shard, the 16384-utterance chunks
        * of the pipelines): the lone filter wavefront is the bound and the one generator wavefront next door takes
@@ -709,7 +711,7 @@ int vs_plan_create_impl(vs_ctx *ctx, const vs_lane *lanes, size_t n_lanes, size_
        * noise wavefront together on the next one (VS_WS_LAYOUT_SPREAD_2X3; with one group per workgroup the three
        * wavefronts have a SIMD each anyway): the generator's work takes 1.84 ms that way.  The role-major layout
        * of two groups would put the open-phase wavefront on the FILTER's SIMD (6.4 ms). */
-      if (wave_specialised && ws_pairs <= 2 && 2 * noisy >= n_lanes && all_deep && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)
+      if (wave_specialised && ws_pairs <= 2 && all_deep && (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)
         ws_roles = 3;
       if (tune->ws_roles == 2) ws_roles = 2;
       if (tune->ws_roles == 3 && (gmap || (size_t)ws_pairs * (size_t)bytes3 <= VS_LDS_LIMIT)) ws_roles = 3;
