@@ -123,7 +123,7 @@ run_step() {
       else
         local key=config${which}; [ "$which" = 4 ] && key=config4_shard
         local lanes=65536; [ "$which" = 4 ] && lanes=32768; [ "$which" = 2 ] && lanes=1024
-        local roles=3; [ "$which" = 2 ] && roles=2
+        local roles=3
         run_step traffic ${key}_exact_$lanes "vs_synth_ws_kernel<0, true, $roles" --config $which || return 1
         run_step sq ${key}_exact_$lanes "vs_synth_ws_kernel<0, true, $roles" --config $which || return 1
         run_step traffic ${key}_fma_$lanes "vs_synth_ws_kernel<1, true, $roles" --config $which --arith fma || return 1
