@@ -196,6 +196,16 @@ class Engine:
     def synchronize(self):
         check(self._lib.vs_ctx_synchronize(self._ctx), "vs_ctx_synchronize")
 
+    def timer_mark(self, which):
+        """vs_ctx_timer_mark(): an event behind what has been enqueued on the context's stream so far (0 = start, 1 = end)"""
+        check(self._lib.vs_ctx_timer_mark(self._ctx, int(which)), "vs_ctx_timer_mark")
+
+    def timer_elapsed(self):
+        """vs_ctx_timer_elapsed(): waits for mark 1, milliseconds of device time from mark 0 to it"""
+        ms = C.c_double()
+        check(self._lib.vs_ctx_timer_elapsed(self._ctx, C.byref(ms)), "vs_ctx_timer_elapsed")
+        return ms.value
+
     def selftest(self):
         """(rc, [division shortcut, philox, isqrt, round2int, noise sample, philox2, wave-to-SIMD dealing, output-noise sample] failure counts)"""
         f = (C.c_uint64 * 8)()
