@@ -15,7 +15,7 @@
 #   tools/gpu.sh diag                           phase breakdown from the diagnostic build
 #   tools/gpu.sh full <tag>                     the round's evidence pass (copy the summaries into profiles/)
 #   tools/gpu.sh configs <tag>                  bench.py --config 2 / 4 / 5 under rocprofv3 --kernel-trace --stats
-#   tools/gpu.sh pmcset 3|3n|2|4|5              traffic + SQ counter passes of one configuration's keys (exact, fma[, f32])
+#   tools/gpu.sh pmcset 3|3n|2|4|5|f            traffic + SQ counter passes of one configuration's keys (exact, fma[, f32]); f = the f32 / vowel -n rows left over
 # Steps may be chained:  tools/gpu.sh test -- ab default r2 -- bench
 # Boxes differ by up to 10 % in sustained clock, so variants are only ever compared within one call.
 set -o pipefail
@@ -120,6 +120,18 @@ run_step() {
         run_step sq config3_onoise_exact_65536 "vs_synth_ws_pow_kernel<0" --vowel-n 20 || return 1
         run_step traffic config3_onoise_noisepass_exact_65536 "vs_out_noise_kernel" --vowel-n 20 || return 1
         run_step sq config3_onoise_noisepass_exact_65536 "vs_out_noise_kernel" --vowel-n 20 || return 1
+      elif [ "$which" = f ]; then
+        # the rows of the bench line's other_configs that the sets above leave out: f32 on configs 2 / 4 / 5, vowel -n in fma and f32
+        for c in 2 4 5; do
+          local k=config$c; [ "$c" = 4 ] && k=config4_shard
+          local n=65536; [ "$c" = 4 ] && n=32768; [ "$c" = 2 ] && n=1024
+          run_step traffic ${k}_f32_$n "vs_synth_ws_kernel<2, true, 3" --config $c --arith f32 || return 1
+          run_step sq ${k}_f32_$n "vs_synth_ws_kernel<2, true, 3" --config $c --arith f32 || return 1
+        done
+        run_step traffic config3_onoise_fma_65536 "vs_synth_ws_pow_kernel<1" --vowel-n 20 --arith fma || return 1
+        run_step sq config3_onoise_fma_65536 "vs_synth_ws_pow_kernel<1" --vowel-n 20 --arith fma || return 1
+        run_step traffic config3_onoise_f32_65536 "vs_synth_ws_pow_kernel<2" --vowel-n 20 --arith f32 || return 1
+        run_step sq config3_onoise_f32_65536 "vs_synth_ws_pow_kernel<2" --vowel-n 20 --arith f32 || return 1
       else
         local key=config${which}; [ "$which" = 4 ] && key=config4_shard
         local lanes=65536; [ "$which" = 4 ] && lanes=32768; [ "$which" = 2 ] && lanes=1024
