@@ -120,7 +120,10 @@ typedef struct vs_cycle_rec {
  *                 tables: 0 differences in 1.05e9 samples of BASELINE config 3 and in 6e8 samples
  *                 of the option fuzz, bound +-1 LSB.  For explicit sets the distance follows the
  *                 set's conditioning (+-1 LSB measured for max |A| <= 500; a direct form of order
- *                 40 with coefficients of 1e4 moves a few samples by more). */
+ *                 40 with coefficients of 1e4 moves a few samples by more).  With the vowel stage's own noise
+ *                 (out_snr, vowel -n) the bound is +-2 LSB: the width of a frame's noise follows the frame's power, which a
+ *                 sample that moved by one LSB moves in its last bits (tools/fuzz_fma.py: 9.6e9 fuzzed samples, 2 LSB in four
+ *                 utterances, all of them with vowel -n). */
 /* VS_ARITH_F32:   the recurrence in single precision, two taps per packed multiply-add -- 1.25 x the speed of VS_ARITH_FMA
  *                 for a MEASURED distance from the reference (single precision is marginal against 1e-5):
  *                 per table at gain 10 / pre-emphasis 1, RMS of full scale 4.6e-6 (table 7) .. 1.9e-5 (/i/), above 1e-5
