@@ -130,7 +130,10 @@ typedef struct vs_cycle_rec {
  *                 for /i/, /u/ and table 1; at most 6 LSB there, 25 LSB for table 5 without pre-emphasis; 7.5e-6 over
  *                 BASELINE config 3's mix of tables.  The whole table
  *                 is tests/golden/f32_bounds.json (made by tools/f32_survey.py on the device); tests/test_gpu_f32.py holds
- *                 the kernels to it.  Only the fused wave-specialised kernels have this arithmetic: source-only and
+ *                 the kernels to it.  The distance is RELATIVE to the filter's state, i.e. it grows with the gain: over the
+ *                 option fuzz's ordinary ranges (gain 1..20) RMS 8.4e-6, at most 61 LSB in 1.2e9 samples; with the corner
+ *                 draws (vowel -g 100 and 1000: a state of 1e5..1e6 that the output clips) RMS 2.0e-5..2.9e-5 and single
+ *                 unclipped samples off by hundreds of LSB, at most 1986 (tools/fuzz_fma.py ... f32, profiles/r06_f32_mode_measured.txt).  Only the fused wave-specialised kernels have this arithmetic: source-only and
  *                 filter-only launches, the one-wave kernel and coefficient sets of 23..40 taps run VS_ARITH_FMA. */
 #define VS_ARITH_EXACT 0
 #define VS_ARITH_FMA 1
