@@ -83,6 +83,14 @@ class PipelinedGather:
         self.chunks = [base[a:b] for a, b in self.edges]
         self.comm_stream = torch.cuda.Stream(device=device) if self.cuda else None
 
+    def _send(self, chunk):
+        """One chunk to the root, as a batch of ONE operation: the root posts its receives as a batch, and on the NCCL/RCCL
+        backend a batched operation travels on the group's communicator of ALL ranks while a lone isend() may be given a
+        two-rank communicator of its own (PyTorch's ProcessGroupNCCL keeps that for single point-to-point calls) -- a send
+        and a receive on different communicators never meet.  Both ends batched: the same communicator whatever the
+        version.  (gloo has no batches: the call falls back to the plain operation.)"""
+        return list(dist.batch_isend_irecv([dist.P2POp(dist.isend, chunk, self.dst)]))
+
     def run(self, launch, progress=None):
         """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done.
         progress (optional) is called once per round of chunks handed to the transport and once per completed
@@ -124,9 +132,9 @@ class PipelinedGather:
                         ev.synchronize()
                     with torch.cuda.stream(self.comm_stream):
                         self.comm_stream.wait_event(ev)
-                        work.append(dist.isend(self.chunks[k], self.dst))
+                        work += self._send(self.chunks[k])
                 else:
-                    work.append(dist.isend(self.chunks[k], self.dst))
+                    work += self._send(self.chunks[k])
             else:
                 ops = [dist.P2POp(dist.irecv, self.full[peer_edges[r][k][0]:peer_edges[r][k][1]], r)
                        for r in peers if k < len(peer_edges[r])]
