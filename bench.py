@@ -419,7 +419,8 @@ def _config_profile(cfg_i, arith_name, n_lanes, out_noise_db, kernel_name, kerne
         rec = None
     if sq and not (prov["valu"]["matches_tree"] and first in str(sq.get("kernel", ""))):
         sq = None
-    out = {"profile_key": key, "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+    out = {"profile_key": key, "of_kernel": first + (" (the first of the launch's kernels only; kernel_ms is all of them)" if " + " in kernel_name else ""),
+           "traffic": rec["hbm_bytes_per_launch"] if rec else None,
            "traffic_matches_tree": bool(prov["traffic"] and prov["traffic"]["matches_tree"]),
            "valu_matches_tree": bool(prov["valu"] and prov["valu"]["matches_tree"])}
     if rec:
