@@ -218,3 +218,16 @@ def test_bench_line_carries_every_baseline_configuration():
     fc = d["fresh_batches_c"]
     assert "error" not in fc and fc["batches"] == 50 and fc["last_batch_equals_a_plain_launch"] is True
     assert fc["plan_destroy_ms_avg"] < 0.5 and 0.9 <= fc["ratio_to_same_plan"] <= 1.12, fc   # (two process starts: a few per cent of noise)
+
+
+def test_pcm_travels_through_rccls_process_group():
+    """One rank over backend "nccl" (= RCCL) on this box's one GPU: the batched send / receive that both ends of
+    voice_synth_amd/dist.py's gather post -- int16 PCM as bytes (wire_view: RCCL's process group refuses int16, which no
+    gloo rehearsal could have shown), on a side stream behind an event -- and the reductions bench.py makes, against the real
+    librccl (tools/rccl_self_probe.py; a send to the rank itself is the only exchange RCCL allows on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_self_probe.py")], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert r.stdout.count("equal") == 3 and "DIFFERENT" not in r.stdout and r.stdout.strip().endswith("ok")

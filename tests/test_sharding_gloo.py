@@ -279,3 +279,17 @@ def test_node_run_preflight_findings():
     assert any("gloo" in w for w in bench.preflight_errors(seen(2, backend="gloo"), 2))
     assert any("communicator sizes" in w for w in bench.preflight_errors(seen(4, size=2), 4))
     assert any("ranks reported" in w for w in bench.preflight_errors(seen(3), 4))
+
+
+def test_pcm_goes_on_the_wire_as_bytes():
+    """int16 PCM is handed to the process group as a byte view of the same memory (RCCL's refuses int16)"""
+    import torch
+    from voice_synth_amd.dist import wire_view
+
+    t = torch.arange(12, dtype=torch.int16).reshape(3, 4)
+    v = wire_view(t[1:])
+    assert v.dtype == torch.uint8 and v.shape == (2, 8) and v.data_ptr() == t[1:].data_ptr()
+    v[0, 0] = 0x7F
+    assert int(t[1, 0]) == (4 & 0xFF00) | 0x7F
+    f = torch.zeros(2, dtype=torch.float32)
+    assert wire_view(f) is f

@@ -13,6 +13,13 @@ import torch.distributed as dist
 from .configs import shard_range  # noqa: F401  (the cut itself needs no torch)
 
 
+def wire_view(t):
+    """The tensor as the transport sees it: PCM is int16, and PyTorch's NCCL/RCCL process group refuses that type
+    ("Input tensor data type is not supported for NCCL process group: Short" -- found by tools/rccl_self_probe.py on the one
+    GPU of a test box, before the first multi-GPU run could): the same memory as bytes, which every backend moves."""
+    return t.view(torch.uint8) if t.dtype == torch.int16 else t
+
+
 def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
     """Gathers row blocks [lanes_r, n_samples] (int16, any device) into one
     [n_lanes_total, n_samples] tensor on rank `dst`; other ranks get None.
@@ -36,12 +43,12 @@ def gather_pcm(local, n_lanes_total, dst=0, chunk_rows=None):
             lo, hi = shard_range(n_lanes_total, r, world)
             step = chunk_rows or max(1, hi - lo)
             for a in range(lo, hi, step):
-                ops.append(dist.P2POp(dist.irecv, out[a:min(hi, a + step)], r))
+                ops.append(dist.P2POp(dist.irecv, wire_view(out[a:min(hi, a + step)]), r))
     else:
         lo, hi = shard_range(n_lanes_total, rank, world)
         step = chunk_rows or max(1, hi - lo)
         for a in range(0, hi - lo, step):
-            ops.append(dist.P2POp(dist.isend, local[a:min(hi - lo, a + step)].contiguous(), dst))
+            ops.append(dist.P2POp(dist.isend, wire_view(local[a:min(hi - lo, a + step)].contiguous()), dst))
     # one coalesced group: with RCCL the seven receives of the root run concurrently, one per
     # xGMI link, instead of one after the other
     for q in dist.batch_isend_irecv(ops):
@@ -89,7 +96,7 @@ class PipelinedGather:
         two-rank communicator of its own (PyTorch's ProcessGroupNCCL keeps that for single point-to-point calls) -- a send
         and a receive on different communicators never meet.  Both ends batched: the same communicator whatever the
         version.  (gloo has no batches: the call falls back to the plain operation.)"""
-        return list(dist.batch_isend_irecv([dist.P2POp(dist.isend, chunk, self.dst)]))
+        return list(dist.batch_isend_irecv([dist.P2POp(dist.isend, wire_view(chunk), self.dst)]))
 
     def run(self, launch, progress=None):
         """Returns the gathered tensor on the root, None elsewhere.  Blocks until delivery is done.
@@ -136,7 +143,7 @@ class PipelinedGather:
                 else:
                     work += self._send(self.chunks[k])
             else:
-                ops = [dist.P2POp(dist.irecv, self.full[peer_edges[r][k][0]:peer_edges[r][k][1]], r)
+                ops = [dist.P2POp(dist.irecv, wire_view(self.full[peer_edges[r][k][0]:peer_edges[r][k][1]]), r)
                        for r in peers if k < len(peer_edges[r])]
                 if ops:
                     if self.cuda:
