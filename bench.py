@@ -460,6 +460,27 @@ def _profile_provenance(traffic_rec, valu_rec):
     return out
 
 
+LINE_OUT = None   # where the JSON line goes (None: sys.stdout); see reserve_stdout
+
+
+def reserve_stdout():
+    """Multi-rank runs: the process's standard output carries ONE line, rank 0's.  RCCL writes a five-line banner (version,
+    host, library path) to STDOUT when the first communicator is made -- seen in tools/rccl_self_probe.py's output -- and
+    whatever else a library prints would land there too: file descriptor 1 is pointed at standard error for the rest of the
+    run, and the line goes to a copy of the original made here."""
+    global LINE_OUT
+    if LINE_OUT is None:
+        sys.stdout.flush()
+        LINE_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def print_line(obj):
+    out = LINE_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def preflight_errors(ranks_seen, world):
     """What is wrong with a node run before anything is timed: [] or the findings -- N ranks must drive N DIFFERENT devices
     (host + PCI bus id), over RCCL, each in a communicator of all N."""
@@ -533,6 +554,7 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:  # launched by torch.distributed.run: one rank per GPU over RCCL
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        reserve_stdout()
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -573,9 +595,9 @@ def main():
         wrong = preflight_errors(ranks_seen, world)
         if wrong:
             if rank == 0:
-                print(json.dumps({"metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref", "value": None,
-                                  "unit": "Msamples/s", "n_gpus": world, "error": "pre-flight: " + "; ".join(wrong),
-                                  "ranks_seen": ranks_seen, "distinct_devices": distinct_devices}), flush=True)
+                print_line({"metric": "synthesised Msamples/s (whole node) at 1/2/4/8 MI355X; RMS vs C ref", "value": None,
+                            "unit": "Msamples/s", "n_gpus": world, "error": "pre-flight: " + "; ".join(wrong),
+                            "ranks_seen": ranks_seen, "distinct_devices": distinct_devices})
             eng.close()
             dist.destroy_process_group()
             sys.exit(5)
@@ -929,7 +951,7 @@ def main():
             if rank == 0 and not printed[0]:
                 printed[0] = True
                 result.update(extra)
-                print(json.dumps(result), flush=True)
+                print_line(result)
 
     leg_done = threading.Event()
     phases = Phases()
@@ -962,7 +984,7 @@ def main():
                     if rank == 0 and not printed[0]:
                         printed[0] = True
                         result["config4"] = dict(phases.partial, error=why)
-                        print(json.dumps(result), flush=True)
+                        print_line(result)
                 os._exit(3)   # a stalled exchange is a finding, not a success
 
     if world > 1 and not args.no_config4:

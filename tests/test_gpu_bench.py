@@ -101,7 +101,11 @@ def test_bench_under_torch_distributed_run():
            "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    # standard output is the ONE line: RCCL's banner (it writes five lines to stdout when a communicator is made) and
+    # anything else a library prints have been sent to standard error (bench.reserve_stdout)
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:8]
+    assert b"RCCL version" not in out.stdout
     _check(lines[-1], 3)
 
 
