@@ -535,6 +535,9 @@ def main():
             sys.exit(launch_ranks(args.gpus))
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
 
+    # dmabuf IPC: on this image RCCL between processes needs it (hipIpcGetMemHandle: invalid argument without); the driver's
+    # environment exports it, this is for a launcher that does not -- read when the HIP runtime starts, i.e. before torch
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
