@@ -11,6 +11,21 @@ for n in (3_000_000, 8_388_607):
     got = eng.synth(sub, n)
     want = po.synth(sub, n, threads=32)
     print(n, len(sub), "lanes: equal", bool(np.array_equal(got, want)))
+# the same with the vowel stage's own noise (vowel -n 20): 3750 frames per row -- on every row (the fused kernel takes the frame
+# powers along, vs_synth_ws_pow_kernel) and on every other row (the streaming pass does the rest)
+for every in (1, 2):
+    specs_n, _, _, _ = configs.config_specs(3, 70, out_noise_db=20.0)
+    ln, _ = vs.lanes_from_specs(specs_n)
+    for i in range(70):
+        if i % every:
+            ln[i].out_snr = 0.0
+    n = 3_000_000
+    plan = eng.plan(ln, n)
+    name = plan.kernel_name(vs.VS_KIND_SYNTH)
+    plan.close()
+    got = eng.synth(ln, n)
+    want = po.synth(ln, n, threads=32)
+    print(n, "vowel -n on every %d. row, %s: equal" % (every, name), bool(np.array_equal(got, want)))
 # one row longer than a staging block into pageable memory must be refused, into pinned memory not
 lane=[lanes[0]]
 got = eng.synth(lane, 9_000_000)   # one row is longer than a staging block: DMA by the runtime into pageable memory
