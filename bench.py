@@ -1252,7 +1252,7 @@ def config4_block(args, eng, dev, stream, rank, world, cus, sync_all, phases):
             launch_chunk(kk, tns)
         torch.cuda.synchronize(dev)
         phases.tick()
-        again = gather_pcm(pg.base, total, dst=0)
+        again = gather_pcm(pg.base, total, dst=0, chunk_rows=GATHER_CHUNK)   # messages of at most 1.4 GB, as the overlapped gather's
         sync_all()
         g2 = time.perf_counter() - g0
         gt = torch.tensor([g2], dtype=torch.float64, device=dev)
