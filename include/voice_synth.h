@@ -418,7 +418,10 @@ int vs_node_shard_range(const vs_node *node, size_t n_lanes, int shard, size_t *
  * memory), _RCCL.  vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call.
  * vs_node_rccl_ranks(): ncclCommCount of the shard's communicator -- the number of ranks RCCL itself says it spans (the
  * node's shard count on a healthy node), 0 while the node is on the peer transport, < 0 on error: what a pre-flight prints
- * next to the PCI bus ids (cli/vs_bench.c --gpus N --rccl). */
+ * next to the PCI bus ids (cli/vs_bench.c --gpus N --rccl).  Switching to the RCCL transport ends with a link check: 64 KiB
+ * from the root's communicator to itself through the entry points the gather uses (group, receive, send), compared byte
+ * for byte; a library that fails it is refused (the ncclResult_t in vs_node_last_rccl_error, or VS_ERR_INTERNAL for bytes
+ * that differ) and the node stays on peer copies. */
 #define VS_NODE_TRANSPORT_PEER 0
 #define VS_NODE_TRANSPORT_RCCL 1
 #define VS_NODE_LINK_SELF 0

@@ -173,6 +173,52 @@ static void vs_node_drop_rccl(vs_node *nd, bool keep_lib)
   memset(&nd->rccl, 0, sizeof(nd->rccl));
 }
 
+/* Before the transport is relied upon: one message from the root's communicator to ITSELF -- the only exchange that needs
+ * no other thread -- through the very entry points the gather uses (GroupStart, Recv, Send, GroupEnd, on the root's receive
+ * stream, bytes as ncclInt8), compared byte for byte.  A librccl whose entry points do not behave as the handful of
+ * prototypes above say (another major version, the wrong library found by the loader) is refused HERE, with the transport
+ * still on peer copies, not in the middle of an exchange; and on a one-GPU box it is what lets the tests run the send and
+ * receive entry points against the real library at all (tests/test_gpu_node.py). */
+static int rccl_link_check(vs_node *nd)
+{
+  enum { CHECK_BYTES = 1 << 16 };
+  unsigned char *host = (unsigned char *)malloc(2 * CHECK_BYTES);
+  void *src = NULL, *dst = NULL;
+  int rc = host ? VS_OK : VS_ERR_NOMEM;
+  hipError_t he = (rc == VS_OK) ? hipSetDevice(nd->device[0]) : hipSuccess;
+  if (rc == VS_OK && he == hipSuccess) he = hipMalloc(&src, CHECK_BYTES);
+  if (rc == VS_OK && he == hipSuccess) he = hipMalloc(&dst, CHECK_BYTES);
+  if (rc == VS_OK && he == hipSuccess) {
+    for (int i = 0; i < CHECK_BYTES; i++) host[i] = (unsigned char)((i * 131 + (i >> 8) + 7) & 0xFF);
+    he = hipMemcpy(src, host, CHECK_BYTES, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemset(dst, 0, CHECK_BYTES);
+  }
+  if (rc == VS_OK && he == hipSuccess) {
+    vs_nccl_comm comm0 = vs_commguard_enter(&nd->guard[0]);
+    if (!comm0) rc = VS_ERR_INTERNAL;
+    else {
+      int ne = nd->rccl.GroupStart();
+      if (ne == 0) ne = nd->rccl.Recv(dst, CHECK_BYTES, VS_NCCL_INT8, 0, comm0, nd->recv);
+      if (ne == 0) ne = nd->rccl.Send(src, CHECK_BYTES, VS_NCCL_INT8, 0, comm0, nd->recv);
+      const int ge = nd->rccl.GroupEnd();
+      vs_commguard_leave(&nd->guard[0]);
+      if (ne == 0) ne = ge;
+      if (ne != 0) {
+        nd->last_rccl_error = ne;
+        rc = VS_ERR_HIP;
+      }
+    }
+    if (rc == VS_OK) he = hipStreamSynchronize(nd->recv);
+    if (rc == VS_OK && he == hipSuccess) he = hipMemcpy(host + CHECK_BYTES, dst, CHECK_BYTES, hipMemcpyDeviceToHost);
+    if (rc == VS_OK && he == hipSuccess && memcmp(host, host + CHECK_BYTES, CHECK_BYTES) != 0) rc = VS_ERR_INTERNAL;
+  }
+  if (rc == VS_OK && he != hipSuccess) rc = VS_ERR_HIP;
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  free(host);
+  return rc;
+}
+
 int vs_node_set_transport(vs_node *nd, int transport)
 {
   if (!nd || (transport != VS_NODE_TRANSPORT_PEER && transport != VS_NODE_TRANSPORT_RCCL)) return VS_ERR_ARG;
@@ -242,6 +288,11 @@ int vs_node_set_transport(vs_node *nd, int transport)
   if (he != hipSuccess) {
     vs_node_drop_rccl(nd, false);
     return VS_ERR_HIP;
+  }
+  const int lc = rccl_link_check(nd);
+  if (lc != VS_OK) {
+    vs_node_drop_rccl(nd, false);
+    return lc;
   }
   nd->transport = transport;
   for (int s = 1; s < S; s++) nd->link[s] = VS_NODE_LINK_RCCL;
