@@ -95,13 +95,17 @@ def test_links_and_the_rccl_transport_on_one_device(engine, batch):
     """What one GPU can show of the RCCL transport: the node opens librccl, creates a communicator of its
     own (one rank), gathers through that code path, and gives the communicator back; logical shards of one
     device are refused (RCCL puts one rank on one device), and a pitched root buffer too (RCCL messages
-    are contiguous).  Sends and receives between devices stay unexercised until a multi-GPU node runs
-    them."""
+    are contiguous).  set_transport() itself ends with the node's link check: 64 KiB from the root's communicator to
+    itself through ncclGroupStart / ncclRecv / ncclSend / ncclGroupEnd, compared byte for byte -- so the entry points the
+    gather's exchange is made of DO run against the real librccl here (a check that fails raises, and rccl_ranks says the
+    communicator stands).  Sends and receives between DIFFERENT devices stay unexercised until a multi-GPU node runs them
+    (DESIGN.md section 7)."""
     lanes, ns, want = batch
     node = vs.Node([0])
     try:
         assert node.link(0) == "self"
-        node.set_transport(vs.Node.TRANSPORT_RCCL)
+        node.set_transport(vs.Node.TRANSPORT_RCCL)     # raises if the link check fails
+        assert node.rccl_ranks(0) == 1 and node.last_rccl_error() == 0
         root = engine.dev_alloc(len(lanes) * ns * 2)
         try:
             node.synth_gather(lanes, ns, root, ns)

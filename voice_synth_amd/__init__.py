@@ -366,6 +366,17 @@ class Node:
             raise VsError(v, "vs_node_link")
         return self.LINKS[v]
 
+    def rccl_ranks(self, shard):
+        """vs_node_rccl_ranks(): ncclCommCount of the shard's communicator (0 on the peer transport)"""
+        v = self._lib.vs_node_rccl_ranks(self._node, int(shard))
+        if v < 0:
+            raise VsError(v, "vs_node_rccl_ranks")
+        return v
+
+    def last_rccl_error(self):
+        """vs_node_last_rccl_error(): the ncclResult_t of the last failing RCCL call (0: none)"""
+        return int(self._lib.vs_node_last_rccl_error(self._node))
+
     def set_shard_tuning(self, shard, **kw):
         """vs_ctx_set_tuning() on the context that serves one shard (vs_node_ctx); no keywords resets"""
         ctx = C.c_void_p()
