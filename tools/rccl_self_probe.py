@@ -51,6 +51,42 @@ for rep in range(3):
     print("batch of irecv + isend to self, %d MB: %s, %.1f ms, %d work object(s)" % (src.numel() * 2 >> 20, "equal" if ok else "DIFFERENT", (time.time() - t0) * 1e3, len(work)), flush=True)
     if not ok:
         sys.exit(1)
+# the ordering PipelinedGather relies on, with the real pieces: the LIBRARY's kernel enqueued on torch's current stream
+# (through the stream handle bench.py hands to vs_ctx_set_stream), a torch event behind it, the side stream waits for the
+# event, RCCL sends the chunk -- a send that did not wait for the kernel would ship the zeros written in front of it
+import voice_synth_amd as vs  # noqa: E402
+from voice_synth_amd import configs  # noqa: E402
+
+rows = 16384
+specs, fs, dur, label = configs.config_specs(3, rows)
+lanes, d = vs.lanes_from_specs(specs)
+ns = vs.num_samples(fs, d)
+eng = vs.Engine(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+plan = eng.plan(lanes, ns)
+want = torch.empty((rows, ns), dtype=torch.int16, device=dev)
+plan.launch(vs.VS_KIND_SYNTH, want.data_ptr(), out_pitch=ns)
+torch.cuda.synchronize(dev)
+chunk = torch.empty_like(want)
+got = torch.empty_like(want)
+for rep in range(3):
+    chunk.zero_()
+    got.fill_(-1)
+    plan.launch(vs.VS_KIND_SYNTH, chunk.data_ptr(), out_pitch=ns)      # enqueued, not waited for
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        work = list(dist.batch_isend_irecv([dist.P2POp(dist.irecv, wire_view(got), 0), dist.P2POp(dist.isend, wire_view(chunk), 0)]))
+    for w in work:
+        w.wait()
+    side.synchronize()
+    torch.cuda.current_stream().synchronize()
+    ok = bool(torch.equal(got, want))
+    print("library kernel -> event -> RCCL send to self, %d x %d samples: %s" % (rows, ns, "equal" if ok else "DIFFERENT"), flush=True)
+    if not ok:
+        sys.exit(1)
+plan.close()
+eng.close()
 dist.barrier()
 dist.destroy_process_group()
 print("ok")
